@@ -1,0 +1,214 @@
+"""ctypes binding of the C ABI in ``include/bwtgpu.h`` plus a Python mirror of the
+reference's public interface (``bwt_forward`` / ``bwt_inverse`` /
+``bwt_forward_process_file`` / ``bwt_inverse_process_file``; reference
+``src/bwt.hpp:9,14`` and ``src/inverse_bwt.hpp:8,13``).
+
+Everything computes on the GPU through ``libbwtgpu.so``.  There is no CPU
+fallback: a missing library or a missing device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libbwtgpu.so")
+
+OK = 0
+ERR_NO_DEVICE = -1
+ERR_INVALID = -2
+ERR_BLOCK_TOO_LARGE = -3
+ERR_WORKSPACE = -4
+ERR_HIP = -5
+ERR_NO_DELIMITER = -6
+ERR_NO_FREE_BYTE = -7
+ERR_INTERNAL = -8
+MAX_BLOCK_SIZE = 2097151
+LEN_NO_DELIMITER = 0xFFFFFFFF
+
+# every symbol include/bwtgpu.h declares
+SYMBOLS = [
+    "bwtgpu_init", "bwtgpu_shutdown", "bwtgpu_device_count", "bwtgpu_last_error",
+    "bwtgpu_num_blocks", "bwtgpu_forward_output_bytes", "bwtgpu_forward_workspace_bytes",
+    "bwtgpu_inverse_workspace_bytes", "bwtgpu_forward_batch_device", "bwtgpu_forward_batch",
+    "bwtgpu_inverse_batch_device", "bwtgpu_inverse_batch", "bwtgpu_presence_device",
+    "bwtgpu_find_unused_byte", "bwtgpu_lowest_clear_bit", "bwtgpu_synth_device",
+    "bwtgpu_alloc_host", "bwtgpu_free_host",
+]
+
+
+class BwtGpuError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("bwtgpu error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+_vp, _sz, _u8, _i, _u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint8, ctypes.c_int, ctypes.c_uint64
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded libbwtgpu.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "bwt_amd/libbwtgpu.so is missing: build it with `python -m bwt_amd.build` "
+            "(hipcc, gfx950). bwt_amd has no CPU path.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.bwtgpu_init.argtypes, L.bwtgpu_init.restype = [_i], _i
+    L.bwtgpu_shutdown.argtypes, L.bwtgpu_shutdown.restype = [], None
+    L.bwtgpu_device_count.argtypes, L.bwtgpu_device_count.restype = [], _i
+    L.bwtgpu_last_error.argtypes, L.bwtgpu_last_error.restype = [], ctypes.c_char_p
+    L.bwtgpu_num_blocks.argtypes, L.bwtgpu_num_blocks.restype = [_sz, _sz], _sz
+    L.bwtgpu_forward_output_bytes.argtypes, L.bwtgpu_forward_output_bytes.restype = [_sz, _sz], _sz
+    L.bwtgpu_forward_workspace_bytes.argtypes, L.bwtgpu_forward_workspace_bytes.restype = [_i, _sz, _sz], _sz
+    L.bwtgpu_inverse_workspace_bytes.argtypes, L.bwtgpu_inverse_workspace_bytes.restype = [_i, _sz, _sz], _sz
+    L.bwtgpu_forward_batch_device.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, _vp, _sz, _vp]
+    L.bwtgpu_forward_batch_device.restype = _i
+    L.bwtgpu_forward_batch.argtypes, L.bwtgpu_forward_batch.restype = [_i, _vp, _sz, _sz, _u8, _vp], _i
+    L.bwtgpu_inverse_batch_device.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, _vp, _vp, _sz, _vp]
+    L.bwtgpu_inverse_batch_device.restype = _i
+    L.bwtgpu_inverse_batch.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, ctypes.POINTER(_sz)]
+    L.bwtgpu_inverse_batch.restype = _i
+    L.bwtgpu_presence_device.argtypes, L.bwtgpu_presence_device.restype = [_i, _vp, _sz, _vp, _vp], _i
+    L.bwtgpu_find_unused_byte.argtypes, L.bwtgpu_find_unused_byte.restype = [_vp, _sz, _vp], _i
+    L.bwtgpu_lowest_clear_bit.argtypes, L.bwtgpu_lowest_clear_bit.restype = [_vp], _i
+    L.bwtgpu_synth_device.argtypes = [_i, _i, _u64, _u64, _vp, _sz, _vp, _sz, _vp]
+    L.bwtgpu_synth_device.restype = _i
+    L.bwtgpu_alloc_host.argtypes, L.bwtgpu_alloc_host.restype = [_sz], _vp
+    L.bwtgpu_free_host.argtypes, L.bwtgpu_free_host.restype = [_vp], None
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().bwtgpu_last_error().decode(errors="replace")
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise BwtGpuError(rc, last_error())
+    return rc
+
+
+def init(n_devices: int = 0) -> int:
+    return check(lib().bwtgpu_init(n_devices))
+
+
+def _as_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def _delim(delimiter) -> int:
+    if isinstance(delimiter, (bytes, bytearray, str)):
+        if len(delimiter) != 1:
+            raise ValueError("delimiter must be a single byte")
+        return delimiter[0] if not isinstance(delimiter, str) else ord(delimiter)
+    return int(delimiter) & 0xFF
+
+
+# ---- host-buffer batch calls ----------------------------------------------------
+def forward_batch(data, block_size: int, delimiter, device: int = 0) -> bytes:
+    """Blocks of `block_size` input bytes -> concatenated (len+1)-byte transformed blocks."""
+    a = _as_u8(data)
+    L = lib()
+    out = np.empty(L.bwtgpu_forward_output_bytes(a.size, block_size) if block_size else 0, dtype=np.uint8)
+    check(L.bwtgpu_forward_batch(device, a.ctypes.data, a.size, block_size, _delim(delimiter), out.ctypes.data))
+    return out.tobytes()
+
+
+def inverse_batch(data, block_size: int, delimiter, device: int = 0) -> bytes:
+    a = _as_u8(data)
+    out = np.empty(max(1, a.size), dtype=np.uint8)
+    n = _sz(0)
+    check(lib().bwtgpu_inverse_batch(device, a.ctypes.data, a.size, block_size, _delim(delimiter),
+                                     out.ctypes.data, ctypes.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def find_unused_byte(data) -> int:
+    """Lowest byte value absent from `data`, or -1 (reference src/bwt.cpp:19-47)."""
+    a = _as_u8(data)
+    mask = (ctypes.c_uint32 * 8)()
+    rc = lib().bwtgpu_find_unused_byte(a.ctypes.data if a.size else None, a.size, mask)
+    if rc == ERR_NO_FREE_BYTE:
+        return -1
+    return check(rc)
+
+
+# ---- mirror of the reference's public interface ---------------------------------
+def bwt_forward(input, delimiter=b"~") -> bytes:
+    """reference src/bwt.hpp:9 -- one block: returns len(input)+1 bytes."""
+    a = _as_u8(input)
+    d = _delim(delimiter)
+    if a.size == 0:
+        return bytes([d])
+    if a.size > MAX_BLOCK_SIZE:
+        raise BwtGpuError(ERR_BLOCK_TOO_LARGE, "input longer than the largest supported block")
+    return forward_batch(a, a.size, d)
+
+
+def bwt_inverse(bwt_str, delimiter=b"~") -> bytes:
+    """reference src/inverse_bwt.hpp:8 -- one block of len+1 bytes -> the text."""
+    a = _as_u8(bwt_str)
+    if a.size == 0:
+        raise BwtGpuError(ERR_NO_DELIMITER, "empty block holds no delimiter")
+    if a.size == 1:
+        return inverse_batch(a, 1, delimiter)
+    return inverse_batch(a, a.size - 1, delimiter)
+
+
+def bwt_forward_process_file(input_file: str, output_file: str, block_size: int) -> int:
+    """reference src/bwt.hpp:14 / src/bwt.cpp:159-237: 0 on success, 1 on error (message on stderr)."""
+    try:
+        with open(input_file, "rb") as f:
+            raw = np.frombuffer(f.read(), dtype=np.uint8)
+    except OSError:
+        print("Error: Could not open input file " + input_file, file=sys.stderr)
+        return 1
+    d = find_unused_byte(raw)
+    if d < 0:
+        print("Error: Cannot find a unique delimiter (all 256 byte values appear in file)", file=sys.stderr)
+        return 1
+    try:
+        out = open(output_file, "wb")
+    except OSError:
+        print("Error: Could not open output file " + output_file, file=sys.stderr)
+        return 1
+    with out:
+        out.write(bytes([d]))
+        if raw.size:
+            out.write(forward_batch(raw, block_size, d))
+    return 0
+
+
+def bwt_inverse_process_file(input_file: str, output_file: str, block_size: int) -> int:
+    """reference src/inverse_bwt.hpp:13 / src/inverse_bwt.cpp:66-99."""
+    try:
+        with open(input_file, "rb") as f:
+            raw = np.frombuffer(f.read(), dtype=np.uint8)
+    except OSError:
+        print("Error: Could not open input file " + input_file, file=sys.stderr)
+        return 1
+    try:
+        out = open(output_file, "wb")
+    except OSError:
+        print("Error: Could not open output file " + output_file, file=sys.stderr)
+        return 1
+    with out:
+        if raw.size == 0:
+            print("Error: Empty input file", file=sys.stderr)
+            return 1
+        try:
+            out.write(inverse_batch(raw[1:], block_size, int(raw[0])))
+        except BwtGpuError as e:
+            print("Error: " + str(e), file=sys.stderr)
+            return 1
+    return 0

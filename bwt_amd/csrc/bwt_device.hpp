@@ -1,0 +1,98 @@
+// bwt_device.cuh -- shared device-side helpers for the gfx950 BWT kernels.
+//
+// Wavefronts are 64 lanes wide on CDNA4; every cross-lane idiom here (ballot masks,
+// shuffles, lane ids) is written for exactly that width.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bwtgpu {
+
+constexpr int kWave = 64;
+constexpr int kMaxDigitBits = 9;            // widest LSD radix digit
+constexpr int kBins = 1 << kMaxDigitBits;   // LDS histogram bins per wave
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ uint64_t lanemask_le() { return (2ull << lane_id()) - 1ull; }
+
+// Bits needed to represent v (0 -> 0, 1 -> 1, 2..3 -> 2, ...).
+__device__ __host__ __forceinline__ int bit_length(uint32_t v) {
+    int b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+// Lanes of this wavefront whose `valid` digit equals mine (bit i set <=> lane i is a
+// peer).  One ballot per digit bit: the wave64 form of a match-any.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool valid) {
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+// Exclusive prefix sum of one value per thread over the workgroup; `total` receives
+// the workgroup sum.  s_wsum needs NT/64 words.  Contains two barriers.
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wsum, uint32_t& total) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == kWave - 1) s_wsum[w] = x;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t t = s_wsum[i];
+        if (i < w) pre += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return pre + x - v;
+}
+
+// Splits m elements over the W waves of a workgroup in contiguous chunks whose
+// length is a multiple of 64 (so every wave iteration is one aligned vector).
+struct Chunking {
+    uint32_t chunk;  // elements per wave
+    uint32_t magic;  // ceil(2^32 / chunk)
+    __device__ __forceinline__ void init(uint32_t m, int W) {
+        uint32_t c = (m + (uint32_t)W - 1u) / (uint32_t)W;
+        c = (c + 63u) & ~63u;
+        if (c == 0) c = 64;
+        chunk = c;
+        magic = 0xFFFFFFFFu / c + 1u;
+    }
+    // pos / chunk without a hardware divide
+    __device__ __forceinline__ uint32_t wave_of(uint32_t pos) const {
+        uint32_t q = __umulhi(pos, magic);
+        if (q * chunk > pos) --q;
+        return q;
+    }
+};
+
+// LSD digit plan for a K-bit key: P = ceil(K / kMaxDigitBits) passes of near-equal width.
+struct DigitPlan {
+    int P, base, rem;
+    __device__ __forceinline__ void init(int K) {
+        P = (K + kMaxDigitBits - 1) / kMaxDigitBits;
+        if (P < 1) P = 1;
+        base = K / P;
+        rem = K % P;
+    }
+    __device__ __forceinline__ int bits(int p) const { return base + (p < rem ? 1 : 0); }
+    __device__ __forceinline__ int shift(int p) const { return p * base + (p < rem ? p : rem); }
+};
+
+}  // namespace bwtgpu

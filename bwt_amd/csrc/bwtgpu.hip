@@ -1,0 +1,541 @@
+// bwtgpu.hip -- C ABI (include/bwtgpu.h) of the gfx950 BWT block codec: launch
+// logic, host-buffer staging, delimiter search and the synthetic-input generator.
+// The transform kernels themselves are in bwt_forward.hpp / bwt_inverse.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "bwt_forward.hpp"
+#include "bwt_inverse.hpp"
+#include "bwtgpu.h"
+
+namespace {
+
+using namespace bwtgpu;
+
+constexpr int kFwdThreads = 512;   // forward: threads per workgroup
+constexpr int kInvThreads = 256;   // inverse table build: threads per workgroup
+constexpr size_t kHeaderBytes = 256;  // workspace header: work queue + status words
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(BWTGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+struct Device {
+    int cus = 0;
+    int fwd_wgs_per_cu = 1;
+    int inv_wgs_per_cu = 1;
+    // grow-only buffers for the host-pointer entry points
+    void* d_in = nullptr;   size_t in_cap = 0;
+    void* d_out = nullptr;  size_t out_cap = 0;
+    void* d_ws = nullptr;   size_t ws_cap = 0;
+    void* d_aux = nullptr;  size_t aux_cap = 0;
+    hipStream_t stream = nullptr;
+    bool ready = false;
+    std::mutex mu;          // one host-pointer call at a time per device
+    std::mutex init_mu;     // guards first-use binding
+};
+
+std::mutex g_mu;
+std::vector<Device*> g_dev;
+
+// Binds device `device` on first use: properties, launch geometry, staging stream.
+int ensure_device(int device);
+
+int check_device(int device) {
+    if (g_dev.empty()) {
+        int rc = bwtgpu_init(0);
+        if (rc < 0) return rc;
+    }
+    if (device < 0 || device >= (int)g_dev.size())
+        return fail(BWTGPU_ERR_NO_DEVICE, "device %d out of range (%d bound)", device, (int)g_dev.size());
+    return ensure_device(device);
+}
+
+int grow(void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return BWTGPU_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    need = (need + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+    HIP_TRY(hipMalloc(p, need));
+    *cap = need;
+    return BWTGPU_OK;
+}
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- forward launch geometry ----------------------------------------------
+struct FwdGeom {
+    size_t nblocks;
+    uint32_t ncap;
+    size_t stride;   // bytes of scratch per workgroup
+    uint32_t grid;
+    size_t bytes;    // whole workspace
+};
+
+FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
+    FwdGeom g;
+    g.nblocks = (total_len + block_size - 1) / block_size;
+    const size_t longest = std::min(total_len, block_size);
+    g.ncap = (uint32_t)round_up(longest + 1, 64);
+    g.stride = round_up((size_t)g.ncap * 20, 256);
+    const size_t max_wgs = (size_t)d.cus * (size_t)d.fwd_wgs_per_cu;
+    g.grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
+    g.bytes = kHeaderBytes + g.stride * g.grid;
+    return g;
+}
+
+struct InvGeom {
+    size_t nblocks;
+    uint32_t tstride;
+    uint32_t build_grid;
+    size_t t_off, drow_off, bytes;
+};
+
+InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
+    InvGeom g;
+    const size_t chunk = block_size + 1;
+    g.nblocks = (total + chunk - 1) / chunk;
+    g.tstride = (uint32_t)round_up(std::min(total, chunk), 64);
+    const size_t max_wgs = (size_t)d.cus * (size_t)d.inv_wgs_per_cu;
+    g.build_grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
+    g.drow_off = kHeaderBytes;
+    g.t_off = round_up(g.drow_off + g.nblocks * 4, 256);
+    g.bytes = g.t_off + (size_t)g.tstride * 4 * g.nblocks;
+    return g;
+}
+
+// ---- delimiter search --------------------------------------------------------
+// 256-bit presence mask of the byte values in data[0..len): reference
+// src/bwt.cpp:19-47 keeps the same information in an unordered_set.
+__global__ __launch_bounds__(256) void presence_kernel(const uint8_t* __restrict__ data, size_t len,
+                                                       uint32_t* __restrict__ presence) {
+    __shared__ uint32_t s_mask[8];
+    if (threadIdx.x < 8) s_mask[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    // head bytes up to 16-byte alignment, then 16 bytes per lane, then the tail
+    const size_t mis = (16 - ((uintptr_t)data & 15)) & 15;
+    const size_t head = mis < len ? mis : len;
+    const size_t nvec = (len - head) / 16;
+    const uint4* v = reinterpret_cast<const uint4*>(data + head);
+    auto mark = [&](uint32_t b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] |= ((b >> 5) == (uint32_t)j) ? (1u << (b & 31)) : 0u;
+    };
+    for (size_t i = tid; i < nvec; i += nthreads) {
+        const uint4 q = v[i];
+        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mark(ws[j] & 255u);
+            mark((ws[j] >> 8) & 255u);
+            mark((ws[j] >> 16) & 255u);
+            mark(ws[j] >> 24);
+        }
+    }
+    const size_t tail0 = head + nvec * 16;
+    for (size_t i = tid; i < head; i += nthreads) mark(data[i]);
+    for (size_t i = tail0 + tid; i < len; i += nthreads) mark(data[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t x = m[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x |= __shfl_xor(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicOr(&s_mask[j], x);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && s_mask[threadIdx.x]) atomicOr(&presence[threadIdx.x], s_mask[threadIdx.x]);
+}
+
+// ---- synthetic inputs --------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix_word(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint8_t synth_random255(uint64_t seed, uint64_t i) {
+    const uint64_t w = splitmix_word(seed, i >> 2);
+    return (uint8_t)((((w >> (16 * (i & 3))) & 0xFFFFull) * 255ull) >> 16);
+}
+__device__ __forceinline__ uint8_t synth_acgt(uint64_t seed, uint64_t i) {
+    const uint64_t w = splitmix_word(seed, i >> 5);
+    const uint32_t s = (uint32_t)(w >> (2 * (i & 31))) & 3u;
+    return (uint8_t)((0x54474341u >> (8 * s)) & 255u);  // "ACGT"
+}
+__global__ __launch_bounds__(256) void synth_kernel(int kind, uint64_t seed, uint64_t offset,
+                                                    uint8_t* __restrict__ out, size_t len,
+                                                    const uint8_t* __restrict__ text, size_t text_len) {
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += nthreads) {
+        const uint64_t i = offset + j;
+        int k = kind;
+        if (kind == 5) {
+            const uint32_t which = (uint32_t)((i >> 20) & 3u);
+            k = which == 0 ? 0 : which == 1 ? 1 : which == 2 ? 2 : 6;
+        }
+        uint8_t b;
+        switch (k) {
+            case 0: b = synth_random255(seed, i); break;
+            case 1: b = synth_acgt(seed, i); break;
+            case 2: b = (uint8_t)('a' + i % 7); break;
+            case 3: b = (uint8_t)'a'; break;
+            case 4: b = synth_random255(seed, i & 63); break;
+            default: b = text[i % text_len]; break;
+        }
+        out[j] = b;
+    }
+}
+
+uint32_t stream_grid(const Device& d, size_t items, int per_block) {
+    const size_t want = (items + per_block - 1) / per_block;
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (size_t)d.cus * 8));
+}
+
+int ensure_device(int device) {
+    Device* d = g_dev[device];
+    std::lock_guard<std::mutex> lock(d->init_mu);
+    if (d->ready) return BWTGPU_OK;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    d->cus = prop.multiProcessorCount;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bwt_forward_kernel<kFwdThreads>, kFwdThreads, 0) ==
+            hipSuccess && occ > 0)
+        d->fwd_wgs_per_cu = occ;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bwt_inverse_build_kernel<kInvThreads>, kInvThreads, 0) ==
+            hipSuccess && occ > 0)
+        d->inv_wgs_per_cu = occ;
+    HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    d->ready = true;
+    return BWTGPU_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+const char* bwtgpu_last_error(void) { return g_err; }
+
+int bwtgpu_init(int n_devices) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_dev.empty()) return (int)g_dev.size();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(BWTGPU_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (n_devices > 0 && n_devices < count) count = n_devices;
+    for (int i = 0; i < count; ++i) g_dev.push_back(new Device);
+    return (int)g_dev.size();
+}
+
+void bwtgpu_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (size_t i = 0; i < g_dev.size(); ++i) {
+        Device* d = g_dev[i];
+        if (hipSetDevice((int)i) != hipSuccess) continue;
+        if (d->d_in) (void)hipFree(d->d_in);
+        if (d->d_out) (void)hipFree(d->d_out);
+        if (d->d_ws) (void)hipFree(d->d_ws);
+        if (d->d_aux) (void)hipFree(d->d_aux);
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+        delete d;
+    }
+    g_dev.clear();
+}
+
+int bwtgpu_device_count(void) { return (int)g_dev.size(); }
+
+size_t bwtgpu_num_blocks(size_t total_len, size_t block_size) {
+    return block_size ? (total_len + block_size - 1) / block_size : 0;
+}
+
+size_t bwtgpu_forward_output_bytes(size_t total_len, size_t block_size) {
+    return total_len + bwtgpu_num_blocks(total_len, block_size);
+}
+
+size_t bwtgpu_forward_workspace_bytes(int device, size_t total_len, size_t block_size) {
+    if (check_device(device) != BWTGPU_OK || block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE) return 0;
+    return fwd_geom(*g_dev[device], total_len, block_size).bytes;
+}
+
+size_t bwtgpu_inverse_workspace_bytes(int device, size_t total, size_t block_size) {
+    if (check_device(device) != BWTGPU_OK || block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE) return 0;
+    return inv_geom(*g_dev[device], total, block_size).bytes;
+}
+
+int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                uint8_t delimiter, uint8_t* d_out, void* d_workspace, size_t workspace_bytes,
+                                void* stream) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE)
+        return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
+                    (size_t)BWTGPU_MAX_BLOCK_SIZE);
+    if (total_len == 0) return BWTGPU_OK;
+    if (!d_in || !d_out || !d_workspace) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+    const Device& d = *g_dev[device];
+    const FwdGeom g = fwd_geom(d, total_len, block_size);
+    if (workspace_bytes < g.bytes)
+        return fail(BWTGPU_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, g.bytes);
+    if (g.nblocks > 0xFFFFFFF0ull) return fail(BWTGPU_ERR_INVALID, "too many blocks in one batch");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
+    FwdArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.total_len = total_len;
+    a.block_size = (uint32_t)block_size;
+    a.nblocks = (uint32_t)g.nblocks;
+    a.ncap = g.ncap;
+    a.delim = delimiter;
+    a.ws = (uint8_t*)d_workspace + kHeaderBytes;
+    a.ws_stride = g.stride;
+    a.queue = (uint32_t*)d_workspace;
+    hipLaunchKernelGGL(bwt_forward_kernel<kFwdThreads>, dim3(g.grid), dim3(kFwdThreads), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return BWTGPU_OK;
+}
+
+int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, size_t block_size,
+                                uint8_t delimiter, uint8_t* d_out, uint32_t* d_out_lens, void* d_workspace,
+                                size_t workspace_bytes, void* stream) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE)
+        return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
+                    (size_t)BWTGPU_MAX_BLOCK_SIZE);
+    if (total == 0) return BWTGPU_OK;
+    if (!d_in || !d_out || !d_out_lens || !d_workspace) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+    const Device& d = *g_dev[device];
+    const InvGeom g = inv_geom(d, total, block_size);
+    if (workspace_bytes < g.bytes)
+        return fail(BWTGPU_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, g.bytes);
+    if (g.nblocks > 0xFFFFFFF0ull) return fail(BWTGPU_ERR_INVALID, "too many blocks in one batch");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
+    InvArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.total_len = total;
+    a.block_size = (uint32_t)block_size;
+    a.nblocks = (uint32_t)g.nblocks;
+    a.delim = delimiter;
+    a.tstride = g.tstride;
+    a.T = (uint32_t*)((uint8_t*)d_workspace + g.t_off);
+    a.drow = (uint32_t*)((uint8_t*)d_workspace + g.drow_off);
+    a.lens = d_out_lens;
+    a.queue = (uint32_t*)d_workspace;
+    hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    const uint32_t walk_grid = (uint32_t)((g.nblocks + kWave - 1) / kWave);
+    hipLaunchKernelGGL(bwt_inverse_walk_kernel, dim3(walk_grid), dim3(kWave), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return BWTGPU_OK;
+}
+
+int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t delimiter,
+                         uint8_t* out) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE)
+        return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
+                    (size_t)BWTGPU_MAX_BLOCK_SIZE);
+    if (total_len == 0) return BWTGPU_OK;
+    if (!in || !out) return fail(BWTGPU_ERR_INVALID, "null host pointer");
+    Device& d = *g_dev[device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    HIP_TRY(hipSetDevice(device));
+    // sub-batches bound the device footprint; blocks are independent so any split is exact
+    const size_t max_sub = std::max<size_t>(block_size, (size_t)1 << 30);
+    const size_t blocks_per_sub = std::max<size_t>(1, max_sub / block_size);
+    for (size_t off = 0; off < total_len;) {
+        const size_t sub = std::min(total_len - off, blocks_per_sub * block_size);
+        const size_t nb = (sub + block_size - 1) / block_size;
+        const FwdGeom g = fwd_geom(d, sub, block_size);
+        if ((rc = grow(&d.d_in, &d.in_cap, sub))) return rc;
+        if ((rc = grow(&d.d_out, &d.out_cap, sub + nb))) return rc;
+        if ((rc = grow(&d.d_ws, &d.ws_cap, g.bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(d.d_in, in + off, sub, hipMemcpyHostToDevice, d.stream));
+        rc = bwtgpu_forward_batch_device(device, (const uint8_t*)d.d_in, sub, block_size, delimiter,
+                                         (uint8_t*)d.d_out, d.d_ws, d.ws_cap, d.stream);
+        if (rc) return rc;
+        const size_t out_off = (off / block_size) * (block_size + 1);
+        HIP_TRY(hipMemcpyAsync(out + out_off, d.d_out, sub + nb, hipMemcpyDeviceToHost, d.stream));
+        uint32_t status[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(status, d.d_ws, sizeof status, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        if (status[1]) return fail(BWTGPU_ERR_INTERNAL, "forward kernel reported status 0x%x", status[1]);
+        off += sub;
+    }
+    return BWTGPU_OK;
+}
+
+int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total, size_t block_size, uint8_t delimiter,
+                         uint8_t* out, size_t* out_len) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE)
+        return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
+                    (size_t)BWTGPU_MAX_BLOCK_SIZE);
+    if (out_len) *out_len = 0;
+    if (total == 0) return BWTGPU_OK;
+    if (!in || !out) return fail(BWTGPU_ERR_INVALID, "null host pointer");
+    Device& d = *g_dev[device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    HIP_TRY(hipSetDevice(device));
+    const size_t chunk = block_size + 1;
+    const size_t max_sub = std::max<size_t>(chunk, (size_t)1 << 30);
+    const size_t blocks_per_sub = std::max<size_t>(1, max_sub / chunk);
+    size_t written = 0;
+    std::vector<uint32_t> lens;
+    for (size_t off = 0; off < total;) {
+        const size_t sub = std::min(total - off, blocks_per_sub * chunk);
+        const InvGeom g = inv_geom(d, sub, block_size);
+        if ((rc = grow(&d.d_in, &d.in_cap, sub))) return rc;
+        if ((rc = grow(&d.d_out, &d.out_cap, sub))) return rc;
+        if ((rc = grow(&d.d_ws, &d.ws_cap, g.bytes))) return rc;
+        if ((rc = grow(&d.d_aux, &d.aux_cap, g.nblocks * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(d.d_in, in + off, sub, hipMemcpyHostToDevice, d.stream));
+        rc = bwtgpu_inverse_batch_device(device, (const uint8_t*)d.d_in, sub, block_size, delimiter,
+                                         (uint8_t*)d.d_out, (uint32_t*)d.d_aux, d.d_ws, d.ws_cap, d.stream);
+        if (rc) return rc;
+        lens.resize(g.nblocks);
+        HIP_TRY(hipMemcpyAsync(lens.data(), d.d_aux, g.nblocks * 4, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        // a block made by the forward transform yields len_b bytes; compact only if one did not
+        bool exact = true;
+        size_t text = 0;
+        for (size_t b = 0; b < g.nblocks; ++b) {
+            const size_t nb = std::min(chunk, sub - b * chunk);
+            if (lens[b] == BWTGPU_LEN_NO_DELIMITER)
+                return fail(BWTGPU_ERR_NO_DELIMITER, "block %zu holds no delimiter byte 0x%02x",
+                            off / chunk + b, delimiter);
+            if (lens[b] != nb - 1) exact = false;
+            text += lens[b];
+        }
+        if (exact) {
+            HIP_TRY(hipMemcpy(out + written, d.d_out, text, hipMemcpyDeviceToHost));
+        } else {
+            size_t w = written;
+            for (size_t b = 0; b < g.nblocks; ++b) {
+                const size_t nb = std::min(chunk, sub - b * chunk);
+                if (lens[b])
+                    HIP_TRY(hipMemcpy(out + w, (uint8_t*)d.d_out + b * block_size + (nb - 1 - lens[b]), lens[b],
+                                      hipMemcpyDeviceToHost));
+                w += lens[b];
+            }
+        }
+        written += text;
+        off += sub;
+    }
+    if (out_len) *out_len = written;
+    return BWTGPU_OK;
+}
+
+int bwtgpu_lowest_clear_bit(const uint32_t presence[8]) {
+    for (int v = 0; v < 256; ++v)
+        if (!((presence[v >> 5] >> (v & 31)) & 1u)) return v;
+    return fail(BWTGPU_ERR_NO_FREE_BYTE, "all 256 byte values occur: no delimiter can be chosen");
+}
+
+int bwtgpu_presence_device(int device, const uint8_t* d_data, size_t len, uint32_t* d_presence, void* stream) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (len == 0) return BWTGPU_OK;
+    if (!d_data || !d_presence) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+    HIP_TRY(hipSetDevice(device));
+    const Device& d = *g_dev[device];
+    hipLaunchKernelGGL(presence_kernel, dim3(stream_grid(d, len, 256 * 64)), dim3(256), 0, (hipStream_t)stream,
+                       d_data, len, d_presence);
+    HIP_TRY(hipGetLastError());
+    return BWTGPU_OK;
+}
+
+int bwtgpu_find_unused_byte(const uint8_t* data, size_t len, uint32_t presence_out[8]) {
+    int rc = check_device(0);
+    if (rc) return rc;
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (len) {
+        if (!data) return fail(BWTGPU_ERR_INVALID, "null host pointer");
+        Device& d = *g_dev[0];
+        std::lock_guard<std::mutex> lock(d.mu);
+        HIP_TRY(hipSetDevice(0));
+        if ((rc = grow(&d.d_aux, &d.aux_cap, 64))) return rc;
+        HIP_TRY(hipMemsetAsync(d.d_aux, 0, 32, d.stream));
+        const size_t step = (size_t)1 << 30;
+        for (size_t off = 0; off < len; off += step) {
+            const size_t sub = std::min(step, len - off);
+            if ((rc = grow(&d.d_in, &d.in_cap, sub))) return rc;
+            HIP_TRY(hipMemcpyAsync(d.d_in, data + off, sub, hipMemcpyHostToDevice, d.stream));
+            if ((rc = bwtgpu_presence_device(0, (const uint8_t*)d.d_in, sub, (uint32_t*)d.d_aux, d.stream))) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(mask, d.d_aux, 32, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+    }
+    if (presence_out) memcpy(presence_out, mask, sizeof mask);
+    return bwtgpu_lowest_clear_bit(mask);
+}
+
+int bwtgpu_synth_device(int device, int kind, uint64_t seed, uint64_t offset, uint8_t* d_out, size_t len,
+                        const uint8_t* d_text, size_t text_len, void* stream) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (kind < 0 || kind > 5) return fail(BWTGPU_ERR_INVALID, "unknown synthetic kind %d", kind);
+    if (kind == 5 && (!d_text || text_len == 0)) return fail(BWTGPU_ERR_INVALID, "kind 5 needs a text sample");
+    if (len == 0) return BWTGPU_OK;
+    if (!d_out) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+    HIP_TRY(hipSetDevice(device));
+    const Device& d = *g_dev[device];
+    hipLaunchKernelGGL(synth_kernel, dim3(stream_grid(d, len, 256 * 16)), dim3(256), 0, (hipStream_t)stream, kind,
+                       seed, offset, d_out, len, d_text, text_len ? text_len : 1);
+    HIP_TRY(hipGetLastError());
+    return BWTGPU_OK;
+}
+
+void* bwtgpu_alloc_host(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(BWTGPU_ERR_HIP, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void bwtgpu_free_host(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

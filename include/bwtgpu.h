@@ -1,0 +1,126 @@
+/*
+ * bwtgpu.h -- C ABI of the MI355X (gfx950) BWT block codec.
+ *
+ * This is the drop-in boundary: the C++ host layer (bwt_amd/host/) implements the
+ * reference's public API -- bwt_forward / bwt_inverse / bwt_*_process_file /
+ * FileProcessor (reference src/bwt.hpp:9,14, src/inverse_bwt.hpp:8,13,
+ * src/file_processor.hpp:9-46) -- on top of the functions below, and any other
+ * language binds the same symbols through its FFI.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++ or framework types;
+ *   - every function returns 0 (BWTGPU_OK) or a negative BWTGPU_ERR_* code, never
+ *     throws or aborts; bwtgpu_last_error() returns a thread-local message;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with BWTGPU_ERR_NO_DEVICE;
+ *   - block framing is the reference's: a forward block of `len` input bytes
+ *     becomes `len + 1` output bytes that contain the delimiter exactly once, at
+ *     the row of the suffix that starts at offset 0 (reference src/bwt.cpp:102-123);
+ *     blocks are independent, block i of a batch reads `in + i*block_size` and
+ *     writes `out + i*(block_size+1)`; only the last block of a batch may be short.
+ *     The on-disk container adds one leading delimiter byte per file
+ *     (reference src/bwt.cpp:131-139); that byte is written by the host layer, not here.
+ *   - "_device" entry points take device pointers, enqueue on `stream` (a hipStream_t
+ *     passed as void*, NULL = the default stream) and return without synchronising;
+ *     the others take host pointers and are synchronous.
+ */
+#ifndef BWTGPU_H
+#define BWTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWTGPU_OK 0
+#define BWTGPU_ERR_NO_DEVICE (-1)      /* no HIP device / bad device index */
+#define BWTGPU_ERR_INVALID (-2)        /* bad argument (NULL pointer, block_size == 0, ...) */
+#define BWTGPU_ERR_BLOCK_TOO_LARGE (-3)/* block_size above BWTGPU_MAX_BLOCK_SIZE */
+#define BWTGPU_ERR_WORKSPACE (-4)      /* workspace too small */
+#define BWTGPU_ERR_HIP (-5)            /* a HIP runtime call failed (see bwtgpu_last_error) */
+#define BWTGPU_ERR_NO_DELIMITER (-6)   /* inverse: a block does not contain the delimiter */
+#define BWTGPU_ERR_NO_FREE_BYTE (-7)   /* all 256 byte values occur: no delimiter can be chosen */
+#define BWTGPU_ERR_INTERNAL (-8)       /* a kernel reported an inconsistent state */
+
+/* Largest supported block_size: block + delimiter must fit 21-bit suffix indices. */
+#define BWTGPU_MAX_BLOCK_SIZE ((size_t)2097151)
+
+/* Value stored in the inverse's per-block length array for a block without delimiter. */
+#define BWTGPU_LEN_NO_DELIMITER 0xFFFFFFFFu
+
+/* ---- lifecycle --------------------------------------------------------- */
+
+/* Binds the library to the first `n_devices` visible HIP devices (0 = all).
+ * Returns the number of devices in use (> 0) or a negative error.  Idempotent. */
+int bwtgpu_init(int n_devices);
+/* Releases cached device buffers and streams. */
+void bwtgpu_shutdown(void);
+/* Number of devices bound by bwtgpu_init (0 before init / without a GPU). */
+int bwtgpu_device_count(void);
+/* Message for the calling thread's most recent error ("" if none). */
+const char* bwtgpu_last_error(void);
+
+/* ---- sizes -------------------------------------------------------------- */
+
+/* Blocks in a forward batch: ceil(total_len / block_size). */
+size_t bwtgpu_num_blocks(size_t total_len, size_t block_size);
+/* Bytes written by a forward batch: total_len + number of blocks. */
+size_t bwtgpu_forward_output_bytes(size_t total_len, size_t block_size);
+/* Device scratch a forward / inverse "_device" call needs for this batch shape. */
+size_t bwtgpu_forward_workspace_bytes(int device, size_t total_len, size_t block_size);
+size_t bwtgpu_inverse_workspace_bytes(int device, size_t total_len_with_delims, size_t block_size);
+
+/* ---- forward: replaces the worker pool of reference src/bwt.cpp:143-156,
+ *      each worker's bwt_forward (src/bwt.cpp:102-123) and build_suffix_array
+ *      (src/bwt.cpp:50-99), for a whole batch of blocks in one launch ---------- */
+int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                uint8_t delimiter, uint8_t* d_out, void* d_workspace,
+                                size_t workspace_bytes, void* stream);
+/* Host buffers: `out` receives total_len + nblocks bytes. */
+int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t block_size,
+                         uint8_t delimiter, uint8_t* out);
+
+/* ---- inverse: replaces the serial loop of reference src/inverse_bwt.cpp:85-95 and
+ *      bwt_inverse (src/inverse_bwt.cpp:13-63) for a whole batch of blocks ------
+ * `in` is the concatenation of (len_i + 1)-byte transformed blocks, i.e. chunks of
+ * block_size + 1 bytes, the last possibly shorter.  Block i's text is written so
+ * that it ENDS at out + i*block_size + len_i; d_out_lens[i] receives its length,
+ * which is len_i for every block produced by the forward transform (then the text
+ * starts exactly at out + i*block_size).  A block with more than one delimiter
+ * yields a shorter text (the reference stops at the first delimiter it walks into,
+ * src/inverse_bwt.cpp:55-57); a block with none yields BWTGPU_LEN_NO_DELIMITER. */
+int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total_len_with_delims,
+                                size_t block_size, uint8_t delimiter, uint8_t* d_out,
+                                uint32_t* d_out_lens, void* d_workspace, size_t workspace_bytes,
+                                void* stream);
+/* Host buffers: `out` must hold total_len_with_delims bytes; *out_len receives the
+ * number of bytes produced (texts of all blocks, concatenated and compacted). */
+int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total_len_with_delims,
+                         size_t block_size, uint8_t delimiter, uint8_t* out, size_t* out_len);
+
+/* ---- delimiter search: replaces reference src/bwt.cpp:19-47 (find_unique_char) --
+ * presence[8] is a 256-bit "byte value occurs" mask (bit v%32 of word v/32).  The
+ * device variant ORs into d_presence (zero it first); callers holding several
+ * shards OR the masks.  Returns the lowest absent value, or
+ * BWTGPU_ERR_NO_FREE_BYTE. */
+int bwtgpu_presence_device(int device, const uint8_t* d_data, size_t len, uint32_t* d_presence,
+                           void* stream);
+int bwtgpu_find_unused_byte(const uint8_t* data, size_t len, uint32_t presence_out[8]);
+int bwtgpu_lowest_clear_bit(const uint32_t presence[8]);
+
+/* ---- synthetic inputs (benchmark / test plumbing) ----------------------------
+ * Writes bytes [offset, offset+len) of stream (kind, seed) to d_out; kinds:
+ * 0 random255, 1 acgt, 2 period7, 3 period1, 4 period64, 5 mixed (needs d_text). */
+int bwtgpu_synth_device(int device, int kind, uint64_t seed, uint64_t offset, uint8_t* d_out,
+                        size_t len, const uint8_t* d_text, size_t text_len, void* stream);
+
+/* ---- pinned host memory for callers that stage their own batches --------------- */
+void* bwtgpu_alloc_host(size_t bytes);
+void bwtgpu_free_host(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BWTGPU_H */

@@ -1,0 +1,161 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Bit-exact is the bar: this is byte and index work.
+
+Run on an MI355X with ``python -m pytest tests -m gpu``.
+"""
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from bwt_amd import api, synth
+from conftest import CORPUS, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return oracle.oracle()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    assert api.init(1) >= 1
+    yield
+
+
+def test_known_answers(known_answers):
+    for v in known_answers:
+        data = bytes.fromhex(v["input_hex"])
+        fwd = api.bwt_forward(data, v["delimiter"])
+        assert fwd.hex() == v["forward_hex"], v["name"]
+        assert api.bwt_inverse(fwd, v["delimiter"]).hex() == v["inverse_hex"], v["name"]
+
+
+def test_synthetic_vectors(synthetic_golden):
+    for row in synthetic_golden:
+        data = synth.generate(row["kind"], row["seed"], row["offset"], row["length"]).tobytes()
+        fwd = api.bwt_forward(data, row["delimiter"])
+        assert hashlib.sha256(fwd).hexdigest() == row["forward_sha256"], row
+        assert api.bwt_inverse(fwd, row["delimiter"]) == data, row
+
+
+def test_random_blocks_against_oracle(orc):
+    rng = random.Random(20251111)
+    for trial in range(120):
+        n = rng.choice([1, 2, 3, 5, 31, 64, 65, 127, 128, 129, 500, 1023, 1024, 1025, 4097, 20000])
+        sigma = rng.choice([1, 2, 3, 4, 16, 100, 255])
+        data = bytes(rng.randrange(sigma) for _ in range(n))
+        delim = 255 if trial % 7 else rng.randrange(256)  # every 7th: a delimiter that may occur in the data
+        want = orc.forward(data, delim)
+        got = api.bwt_forward(data, delim)
+        assert got == want, (trial, n, sigma, delim)
+        assert api.bwt_inverse(want, delim) == orc.inverse(want, delim), (trial, n, sigma, delim)
+
+
+def test_batches_with_ragged_tail(orc):
+    rng = np.random.default_rng(5)
+    for total, bs in [(1, 1), (10, 1), (10, 3), (4096, 1024), (4097, 1024), (5000, 512), (100000, 4096),
+                      (300000, 65536), (70000, 70000), (70001, 70000)]:
+        data = rng.integers(0, 200, size=total, dtype=np.uint8).tobytes()
+        want = orc.forward_buffer(data, bs, 4)
+        delim = want[0]
+        got = api.forward_batch(data, bs, delim)
+        assert got == want[1:], (total, bs)
+        assert api.inverse_batch(got, bs, delim) == data, (total, bs)
+
+
+def test_inverse_errors_and_misuse(orc):
+    with pytest.raises(api.BwtGpuError) as e:
+        api.bwt_inverse(b"abcdef", ord("~"))
+    assert e.value.code == api.ERR_NO_DELIMITER
+    # several delimiters: the walk starts at the last one and stops at the first it reaches
+    for blk in [b"~~aabb", b"~~~", b"a~b~c~", b"~"]:
+        assert api.bwt_inverse(blk, ord("~")) == orc.inverse(blk, ord("~")), blk
+    with pytest.raises(api.BwtGpuError) as e:
+        api.forward_batch(b"abc", 0, 0)
+    assert e.value.code == api.ERR_INVALID
+    with pytest.raises(api.BwtGpuError) as e:
+        api.forward_batch(b"abc", api.MAX_BLOCK_SIZE + 1, 0)
+    assert e.value.code == api.ERR_BLOCK_TOO_LARGE
+
+
+def test_find_unused_byte():
+    assert api.find_unused_byte(b"") == 0
+    assert api.find_unused_byte(bytes(range(256))) == -1
+    assert api.find_unused_byte(bytes(range(255)) * 1000) == 255
+    rng = np.random.default_rng(1)
+    for n in [1, 15, 16, 17, 1000, 123457]:
+        a = rng.integers(0, 256, size=n, dtype=np.uint8)
+        a[a == 77] = 78
+        a[a == 3] = 4
+        present = set(a.tolist())
+        want = next((v for v in range(256) if v not in present), -1)
+        assert api.find_unused_byte(a[1:]) == next((v for v in range(256) if v not in set(a[1:].tolist())), -1)
+        assert api.find_unused_byte(a) == want
+
+
+def test_corpus_files(corpus_golden, tmp_path):
+    """Whole-file forward bytes equal the reference's (SHA-256), every corpus file."""
+    for row in corpus_golden["files"]:
+        if row["block_size"] < 4096:
+            continue  # tiny-block sweep is covered by test_small_block_sweep on two files
+        src = os.path.join(CORPUS, row["file"])
+        f, b = str(tmp_path / "f.bwt"), str(tmp_path / "f.out")
+        rc = api.bwt_forward_process_file(src, f, row["block_size"])
+        assert rc == row["rc"], row
+        if rc:
+            continue
+        out = open(f, "rb").read()
+        assert len(out) == row["output_bytes"] and out[0] == row["delimiter"]
+        assert hashlib.sha256(out).hexdigest() == row["sha256"], (row["file"], row["block_size"])
+        assert api.bwt_inverse_process_file(f, b, row["block_size"]) == 0
+        assert open(b, "rb").read() == open(src, "rb").read()
+
+
+def test_small_block_sweep(corpus_golden, tmp_path):
+    for row in corpus_golden["files"]:
+        if row["block_size"] >= 4096 or row["file"] not in ("fields.c", "sum"):
+            continue
+        src = os.path.join(CORPUS, row["file"])
+        f = str(tmp_path / "f.bwt")
+        assert api.bwt_forward_process_file(src, f, row["block_size"]) == 0
+        assert hashlib.sha256(open(f, "rb").read()).hexdigest() == row["sha256"], row
+
+
+def test_alice29_128k_full_vector():
+    raw = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    want = open(os.path.join(GOLDEN, "alice29_128k.bwt"), "rb").read()
+    assert api.forward_batch(raw, 131072, want[0]) == want[1:]
+    assert api.inverse_batch(want[1:], 131072, want[0]) == raw
+
+
+def test_file_edge_cases(corpus_golden, tmp_path):
+    for e in corpus_golden["edge"]:
+        raw = bytes.fromhex(e["input_hex"])
+        src, f, b = str(tmp_path / "e.in"), str(tmp_path / "e.bwt"), str(tmp_path / "e.out")
+        open(src, "wb").write(raw)
+        assert api.bwt_forward_process_file(src, f, e["block_size"]) == e["rc"]
+        assert open(f, "rb").read().hex() == e["output_hex"], e["name"]
+        assert api.bwt_inverse_process_file(f, b, e["block_size"]) == 0
+        assert open(b, "rb").read() == raw
+    empty = str(tmp_path / "empty")
+    open(empty, "wb").close()
+    assert api.bwt_inverse_process_file(empty, str(tmp_path / "x"), 1024) == 1  # reference src/inverse_bwt.cpp:78-82
+
+
+@pytest.mark.parametrize("kind,bs", [("random255", 65536), ("acgt", 262144), ("period7", 262144),
+                                     ("period1", 65536), ("period64", 131072), ("acgt", 1048576)])
+def test_benchmark_shapes_against_oracle(orc, kind, bs):
+    """A few blocks of each benchmark configuration, byte-for-byte against the oracle."""
+    total = 2 * bs + 12345
+    data = synth.generate(kind, synth.base_seed(2), 1000, total).tobytes()
+    want = orc.forward_buffer(data, bs, 8)
+    delim = want[0]
+    got = api.forward_batch(data, bs, delim)
+    assert got == want[1:]
+    assert api.inverse_batch(got, bs, delim) == data
