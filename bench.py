@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Round-trip BWT throughput on MI355X: forward + inverse over a synthetic shard that is
+already resident in HBM, one process per GPU, blocks sharded across ranks (no collective
+on the data path -- blocks are independent).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one forward pass plus one inverse pass of the hot path over the rank's whole
+shard.  Rank 0 prints ONE JSON line.  `value` is input bytes of all ranks per second of
+(forward + inverse), GB = 1e9 bytes.  `roofline` prices the dominant kernel (the forward
+suffix-sort kernel) at its algorithmic bytes (read N, write N + nblocks per launch) over
+its HIP-event duration; `cpu_baseline` times the reference CPU implementation on a bounded
+sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GIB = 1 << 30
+MIB = 1 << 20
+HBM_PEAK = 8.0e12  # bytes/s, MI355X HBM3E
+
+# name -> (kind, block_size, bytes per GPU, config id for the seed, description)
+WORKLOADS = {
+    "acgt-4g-256k": ("acgt", 256 * 1024, 4 * GIB, 3, "4 GiB synthetic ACGT text, 256 KiB blocks (BASELINE configs[2])"),
+    "random-1g-64k": ("random255", 64 * 1024, 1 * GIB, 2, "1 GiB uniform bytes over 0x00-0xFE, 64 KiB blocks (BASELINE configs[1])"),
+    "period7-1g-256k": ("period7", 256 * 1024, 1 * GIB, 4, "1 GiB period-7 text, 256 KiB blocks (BASELINE configs[3])"),
+    "mixed-4g-1m": ("mixed", 1024 * 1024, 4 * GIB, 5, "4 GiB-per-GPU slice of the mixed corpus, 1 MiB blocks (BASELINE configs[4], sharded)"),
+}
+DEFAULT_WORKLOAD = "acgt-4g-256k"
+METRIC = "round-trip BWT GB/s at 256KB blocks, 1/8xMI355X; % of HBM roofline"
+
+
+def cpu_baseline_worker(kind: str, block_size: int, sample: int, seed: int, ncores: int) -> None:
+    """Child process: time the CPU reference on `sample` bytes, file to file (as the
+    reference's own benchmark does, reference tests/performance.cpp:84-117)."""
+    avail = sorted(os.sched_getaffinity(0))
+    os.sched_setaffinity(0, set(avail[:ncores]))  # hardware_concurrency() follows the affinity mask
+    import oracle
+    from bwt_amd import synth
+
+    text = open(os.path.join(ROOT, "data", "canterbury_corpus", "alice29.txt"), "rb").read()
+    data = synth.generate(kind, seed, 0, sample, text=text)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as tmp:
+        src, fwd, back = (os.path.join(tmp, n) for n in ("in", "fwd", "back"))
+        data.tofile(src)
+        if oracle.have_reference():
+            impl, kind_name = oracle.reference(), "reference"
+            run_f = lambda: impl.forward_file(src, fwd, block_size)
+        else:
+            impl, kind_name = oracle.oracle(), "port"
+            run_f = lambda: impl.forward_file(src, fwd, block_size, ncores)
+        t0 = time.perf_counter()
+        rc1 = run_f()
+        t1 = time.perf_counter()
+        rc2 = impl.inverse_file(fwd, back, block_size)
+        t2 = time.perf_counter()
+        ok = rc1 == 0 and rc2 == 0 and open(back, "rb").read() == data.tobytes()
+        import hashlib
+
+        digest = hashlib.sha256(open(fwd, "rb").read()[1:]).hexdigest() if rc1 == 0 else ""
+    print(json.dumps({"value": sample / (t2 - t0) / 1e9, "unit": "GB/s", "cores": len(avail[:ncores]),
+                      "kind": kind_name, "forward_s": t1 - t0, "inverse_s": t2 - t1, "roundtrip_ok": ok,
+                      "forward_sha256": digest,
+                      "sample": "first %d MiB of the workload, file to file in tmpfs" % (sample // MIB)}))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--bytes-per-gpu", type=int, default=0, help="override the shard size (bytes)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", nargs=5, metavar=("KIND", "BS", "SAMPLE", "SEED", "CORES"))
+    args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        k, bs, sample, seed, cores = args.cpu_baseline_worker
+        cpu_baseline_worker(k, int(bs), int(sample), int(seed), int(cores))
+        return
+
+    import torch
+    import torch.distributed as dist
+
+    from bwt_amd import api, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    kind, bs, nbytes, cfg, desc = WORKLOADS[args.workload]
+    if args.bytes_per_gpu:
+        nbytes = args.bytes_per_gpu
+    seed = synth.base_seed(cfg)
+    L = api.lib()
+    api.init(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    nblocks = L.bwtgpu_num_blocks(nbytes, bs)
+    fwd_bytes = nbytes + nblocks
+
+    def dptr(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    # ---- shard `rank` of the global synthetic stream, generated in HBM -------------------------
+    text = open(os.path.join(ROOT, "data", "canterbury_corpus", "alice29.txt"), "rb").read()
+    d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    d_in = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d_fwd = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+    d_back = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d_lens = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    ws_f = L.bwtgpu_forward_workspace_bytes(local_rank, nbytes, bs)
+    ws_i = L.bwtgpu_inverse_workspace_bytes(local_rank, fwd_bytes, bs)
+    d_ws_f = torch.empty(ws_f, dtype=torch.uint8, device=dev)
+    d_ws_i = torch.empty(ws_i, dtype=torch.uint8, device=dev)
+    api.check(L.bwtgpu_synth_device(local_rank, synth.KINDS[kind], seed, rank * nbytes, dptr(d_in), nbytes,
+                                    dptr(d_text), d_text.numel(), stream))
+    # delimiter: lowest byte value absent from the WHOLE dataset = OR of the shards' presence masks
+    d_mask = torch.zeros(8, dtype=torch.int32, device=dev)
+    api.check(L.bwtgpu_presence_device(local_rank, dptr(d_in), nbytes, dptr(d_mask), stream))
+    if world > 1:
+        dist.all_reduce(d_mask, op=dist.ReduceOp.BOR)  # 32 bytes, set-up only: not on the timed path
+    mask = (ctypes.c_uint32 * 8)(*[v & 0xFFFFFFFF for v in d_mask.cpu().tolist()])
+    delim = api.check(L.bwtgpu_lowest_clear_bit(mask))
+
+    def forward():
+        api.check(L.bwtgpu_forward_batch_device(local_rank, dptr(d_in), nbytes, bs, delim, dptr(d_fwd), dptr(d_ws_f),
+                                                d_ws_f.numel(), stream))
+
+    def inverse():
+        api.check(L.bwtgpu_inverse_batch_device(local_rank, dptr(d_fwd), fwd_bytes, bs, delim, dptr(d_back),
+                                                dptr(d_lens), dptr(d_ws_i), d_ws_i.numel(), stream))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        forward()
+        inverse()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        forward()
+        ev[s][1].record()
+        inverse()
+        ev[s][2].record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    # ---- checks outside the timed region ------------------------------------------------------
+    roundtrip_ok = bool(torch.equal(d_in, d_back))
+    lens_ok = bool((d_lens[:-1] == bs).all().item()) and int(d_lens[-1].item()) == nbytes - (nblocks - 1) * bs
+    status = d_ws_f[:8].cpu().numpy().view("uint32")  # [1] = forward kernel error flags
+    ok = torch.tensor([int(roundtrip_ok and lens_ok and int(status[1]) == 0)], device=dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    all_ok = bool(ok.item())
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            sample = min(nbytes, args.cpu_sample_mib * MIB)
+            sample -= sample % bs
+            try:
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", kind,
+                                      str(bs), str(sample), str(seed), "16"], capture_output=True, text=True,
+                                     timeout=900, check=True).stdout.strip().splitlines()[-1]
+                cpu = json.loads(out)
+                # the GPU's forward bytes for the same prefix must equal the CPU reference's
+                import hashlib
+
+                nb_s = sample // bs
+                gpu_prefix = d_fwd[:sample + nb_s].cpu().numpy().tobytes()
+                cpu["gpu_forward_matches"] = (hashlib.sha256(gpu_prefix).hexdigest() == cpu.pop("forward_sha256"))
+            except Exception as exc:  # the baseline is a reported number, never a reason to lose the GPU line
+                cpu = {"error": str(exc)[:200]}
+        total_in = nbytes * world
+        step_s = elapsed / args.steps
+        algo_fwd = nbytes + fwd_bytes  # forward kernel: reads N, writes N + nblocks
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": METRIC,
+            "value": total_in / step_s / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "description": desc, "block_size": bs,
+                       "bytes_per_gpu": nbytes, "blocks_per_gpu": nblocks, "delimiter": delim,
+                       "parallelism": "block-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "bwt_forward_kernel", "achieved": algo_fwd / (fwd_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo_fwd / (fwd_ms * 1e-3) / HBM_PEAK,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_fwd, "avg_launch_ms": fwd_ms},
+            "cpu_baseline": cpu,
+            "forward_ms": fwd_ms,
+            "inverse_ms": inv_ms,
+            "forward_GBps": nbytes / (fwd_ms * 1e-3) / 1e9,
+            "inverse_GBps": nbytes / (inv_ms * 1e-3) / 1e9,
+            "roundtrip_pct_of_hbm_roofline": 100.0 * (4 * nbytes + 2 * nblocks) * world / step_s / (HBM_PEAK * world),
+            "roundtrip_verified": all_ok,
+            "kernel_status": int(status[1]),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not all_ok:
+        raise SystemExit("round trip did not reproduce the input")
+
+
+if __name__ == "__main__":
+    main()

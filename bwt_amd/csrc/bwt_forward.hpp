@@ -15,7 +15,7 @@
 //      element (so a final rank IS the suffix-array position); suffixes alone in
 //      their group are finished and leave the working set (wave-ballot + prefix-
 //      count compaction); survivors get a dense group id g.
-//   3. round r >= 1 (prefix length h doubles): element = g | rank[i+h] | i for the
+//   3. round r >= 1 (prefix length h doubles): element = g | rank[i+h]+1 | i for the
 //      survivors only; LSD radix sort on (g, rank[i+h]); rerank inside the old
 //      groups; repeat until no survivor is left.
 //   4. gather: out[rank[i]] = s[i-1] (the delimiter for i == 0, which lands on the
@@ -313,7 +313,11 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     __syncthreads();
     uint64_t* cur = radix_sort<NT>(bufA, bufB, n, ibits, plan, sh.histA, sh.histB, sh.wsum, &queue[1]);
     uint64_t* alt = (cur == bufA) ? bufB : bufA;
-    const int gshift = 2 * ibits;  // element layout for rounds >= 1: g | rank[i+h] | i
+    // element layout for rounds >= 1: g | r2 | i, where r2 = rank[i+h] + 1, or 0 when the
+    // suffix ends exactly at i+h (possible only if the delimiter also occurs inside the
+    // block): "past the end" orders before every real rank, as in src/bwt.cpp:77-79
+    const int rbits = bit_length(n);
+    const int gshift = ibits + rbits;
     uint32_t m, G;
     rerank<NT, true>(cur, alt, rank, n, ibits, gshift, sh, m, G);
 
@@ -325,7 +329,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             break;
         }
         const int gbits = max(1, bit_length(G - 1));
-        plan.init(ibits + gbits);
+        plan.init(rbits + gbits);
         zero_hist<NT>(sh.histA);
         __syncthreads();
         {
@@ -339,7 +343,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
                 if (k < hi) {
                     uint64_t e = alt[k];
                     const uint32_t idx = (uint32_t)(e & imask);
-                    const uint32_t r2 = (idx + h < n) ? rank[idx + h] : 0u;
+                    const uint32_t r2 = (idx + h < n) ? rank[idx + h] + 1u : 0u;
                     e |= (uint64_t)r2 << ibits;
                     alt[k] = e;
                     atomicAdd(&sh.histA[w * kBins + ((uint32_t)(e >> ibits) & dmask)], 1u);
