@@ -95,7 +95,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from bwt_amd import api, synth
+    from bwt_amd import api, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -139,10 +139,10 @@ def main() -> None:
     # delimiter: lowest byte value absent from the WHOLE dataset = OR of the shards' presence masks
     d_mask = torch.zeros(8, dtype=torch.int32, device=dev)
     api.check(L.bwtgpu_presence_device(local_rank, dptr(d_in), nbytes, dptr(d_mask), stream))
-    if world > 1:
-        dist.all_reduce(d_mask, op=dist.ReduceOp.BOR)  # 32 bytes, set-up only: not on the timed path
-    mask = (ctypes.c_uint32 * 8)(*[v & 0xFFFFFFFF for v in d_mask.cpu().tolist()])
-    delim = api.check(L.bwtgpu_lowest_clear_bit(mask))
+    flags = shard.mask_words_to_flags([v & 0xFFFFFFFF for v in d_mask.cpu().tolist()])
+    delim = shard.agree_on_delimiter(flags, device=dev)  # 256 flags, set-up only: not on the timed path
+    if delim < 0:
+        raise SystemExit("the workload uses all 256 byte values: the format has no delimiter for it")
 
     def forward():
         api.check(L.bwtgpu_forward_batch_device(local_rank, dptr(d_in), nbytes, bs, delim, dptr(d_fwd), dptr(d_ws_f),

@@ -37,6 +37,8 @@ SYMBOLS = [
     "bwtgpu_inverse_batch_device", "bwtgpu_inverse_batch", "bwtgpu_presence_device",
     "bwtgpu_find_unused_byte", "bwtgpu_lowest_clear_bit", "bwtgpu_synth_device",
     "bwtgpu_alloc_host", "bwtgpu_free_host",
+    "bwtgpu_pipeline_create", "bwtgpu_pipeline_input", "bwtgpu_pipeline_input_capacity",
+    "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
 ]
 
 
@@ -82,6 +84,13 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_synth_device.restype = _i
     L.bwtgpu_alloc_host.argtypes, L.bwtgpu_alloc_host.restype = [_sz], _vp
     L.bwtgpu_free_host.argtypes, L.bwtgpu_free_host.restype = [_vp], None
+    L.bwtgpu_pipeline_create.argtypes, L.bwtgpu_pipeline_create.restype = [_i, _i, _sz, _sz, _i], _vp
+    L.bwtgpu_pipeline_input.argtypes, L.bwtgpu_pipeline_input.restype = [_vp, _i], _vp
+    L.bwtgpu_pipeline_input_capacity.argtypes, L.bwtgpu_pipeline_input_capacity.restype = [_vp], _sz
+    L.bwtgpu_pipeline_submit.argtypes, L.bwtgpu_pipeline_submit.restype = [_vp, _i, _sz, _u8], _i
+    L.bwtgpu_pipeline_collect.argtypes = [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]
+    L.bwtgpu_pipeline_collect.restype = _i
+    L.bwtgpu_pipeline_destroy.argtypes, L.bwtgpu_pipeline_destroy.restype = [_vp], None
     _lib = L
     return L
 

@@ -235,6 +235,70 @@ int ensure_device(int device) {
     return BWTGPU_OK;
 }
 
+// ---- slab pipeline ------------------------------------------------------------
+struct PipeSlot {
+    uint8_t* h_in = nullptr;
+    uint8_t* h_out = nullptr;
+    uint32_t* h_lens = nullptr;   // inverse: per-block text lengths; forward: [0..1] status words
+    uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    uint32_t* d_lens = nullptr;
+    void* d_ws = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    size_t in_bytes = 0;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct bwtgpu_pipeline {
+    int device = 0;
+    int direction = 0;
+    size_t block_size = 0;
+    size_t slab_blocks = 0;
+    size_t in_cap = 0, out_cap = 0, ws_bytes = 0;
+    uint8_t delimiter = 0;
+    std::vector<PipeSlot> slots;
+};
+
+namespace {
+
+void pipeline_free(bwtgpu_pipeline* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (PipeSlot& s : p->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.h_lens) (void)hipHostFree(s.h_lens);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.d_lens) (void)hipFree(s.d_lens);
+        if (s.d_ws) (void)hipFree(s.d_ws);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete p;
+}
+
+int pipeline_alloc(bwtgpu_pipeline* p, int depth) {
+    HIP_TRY(hipSetDevice(p->device));
+    p->slots.resize((size_t)depth);
+    for (PipeSlot& s : p->slots) {
+        HIP_TRY(hipHostMalloc((void**)&s.h_in, p->in_cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&s.h_out, p->out_cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&s.h_lens, (p->slab_blocks + 2) * 4, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&s.d_in, p->in_cap));
+        HIP_TRY(hipMalloc((void**)&s.d_out, p->out_cap));
+        HIP_TRY(hipMalloc((void**)&s.d_lens, (p->slab_blocks + 2) * 4));
+        HIP_TRY(hipMalloc(&s.d_ws, p->ws_bytes));
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    return BWTGPU_OK;
+}
+
 }  // namespace
 
 // =============================================================================
@@ -524,6 +588,115 @@ int bwtgpu_synth_device(int device, int kind, uint64_t seed, uint64_t offset, ui
     HIP_TRY(hipGetLastError());
     return BWTGPU_OK;
 }
+
+bwtgpu_pipeline* bwtgpu_pipeline_create(int device, int direction, size_t block_size, size_t slab_blocks,
+                                        int depth) {
+    if (check_device(device)) return nullptr;
+    if (block_size == 0 || slab_blocks == 0 || depth < 1 || (direction != BWTGPU_FORWARD && direction != BWTGPU_INVERSE)) {
+        fail(BWTGPU_ERR_INVALID, "bad pipeline shape (block_size %zu, slab_blocks %zu, depth %d)", block_size,
+             slab_blocks, depth);
+        return nullptr;
+    }
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE) {
+        fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
+             (size_t)BWTGPU_MAX_BLOCK_SIZE);
+        return nullptr;
+    }
+    bwtgpu_pipeline* p = new bwtgpu_pipeline;
+    p->device = device;
+    p->direction = direction;
+    p->block_size = block_size;
+    p->slab_blocks = slab_blocks;
+    const Device& d = *g_dev[device];
+    if (direction == BWTGPU_FORWARD) {
+        p->in_cap = slab_blocks * block_size;
+        p->out_cap = slab_blocks * (block_size + 1);
+        p->ws_bytes = fwd_geom(d, p->in_cap, block_size).bytes;
+    } else {
+        p->in_cap = slab_blocks * (block_size + 1);
+        p->out_cap = slab_blocks * block_size;
+        p->ws_bytes = inv_geom(d, p->in_cap, block_size).bytes;
+    }
+    if (pipeline_alloc(p, depth) != BWTGPU_OK) {
+        pipeline_free(p);
+        return nullptr;
+    }
+    return p;
+}
+
+uint8_t* bwtgpu_pipeline_input(bwtgpu_pipeline* p, int slot) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return nullptr;
+    return p->slots[(size_t)slot].h_in;
+}
+
+size_t bwtgpu_pipeline_input_capacity(const bwtgpu_pipeline* p) { return p ? p->in_cap : 0; }
+
+int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    PipeSlot& s = p->slots[(size_t)slot];
+    if (s.busy) return fail(BWTGPU_ERR_INVALID, "slot %d submitted again before it was collected", slot);
+    if (bytes > p->in_cap) return fail(BWTGPU_ERR_INVALID, "%zu bytes exceed the slab capacity %zu", bytes, p->in_cap);
+    HIP_TRY(hipSetDevice(p->device));
+    s.in_bytes = bytes;
+    p->delimiter = delimiter;
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
+        int rc;
+        if (p->direction == BWTGPU_FORWARD) {
+            rc = bwtgpu_forward_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_ws,
+                                             p->ws_bytes, s.stream);
+            if (rc) return rc;
+            const size_t nb = (bytes + p->block_size - 1) / p->block_size;
+            HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, bytes + nb, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipMemcpyAsync(s.h_lens, s.d_ws, 8, hipMemcpyDeviceToHost, s.stream));
+        } else {
+            rc = bwtgpu_inverse_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_lens,
+                                             s.d_ws, p->ws_bytes, s.stream);
+            if (rc) return rc;
+            const size_t nb = (bytes + p->block_size) / (p->block_size + 1);
+            if (bytes > nb) HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, bytes - nb, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipMemcpyAsync(s.h_lens, s.d_lens, nb * 4, hipMemcpyDeviceToHost, s.stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(s.done, s.stream));
+    s.busy = true;
+    return BWTGPU_OK;
+}
+
+int bwtgpu_pipeline_collect(bwtgpu_pipeline* p, int slot, const uint8_t** out, size_t* out_bytes) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size() || !out || !out_bytes)
+        return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    PipeSlot& s = p->slots[(size_t)slot];
+    if (!s.busy) return fail(BWTGPU_ERR_INVALID, "slot %d collected without a submit", slot);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(s.done));
+    s.busy = false;
+    *out = s.h_out;
+    *out_bytes = 0;
+    if (s.in_bytes == 0) return BWTGPU_OK;
+    if (p->direction == BWTGPU_FORWARD) {
+        if (s.h_lens[1]) return fail(BWTGPU_ERR_INTERNAL, "forward kernel reported status 0x%x", s.h_lens[1]);
+        *out_bytes = s.in_bytes + (s.in_bytes + p->block_size - 1) / p->block_size;
+        return BWTGPU_OK;
+    }
+    const size_t chunk = p->block_size + 1;
+    const size_t nb = (s.in_bytes + chunk - 1) / chunk;
+    size_t w = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        const size_t n = std::min(chunk, s.in_bytes - b * chunk);
+        const uint32_t len = s.h_lens[b];
+        if (len == BWTGPU_LEN_NO_DELIMITER)
+            return fail(BWTGPU_ERR_NO_DELIMITER, "block %zu of the slab holds no delimiter byte 0x%02x", b,
+                        p->delimiter);
+        const size_t from = b * p->block_size + (n - 1 - len);  // texts are right-aligned in their slot
+        if (from != w && len) memmove(s.h_out + w, s.h_out + from, len);
+        w += len;
+    }
+    *out_bytes = w;
+    return BWTGPU_OK;
+}
+
+void bwtgpu_pipeline_destroy(bwtgpu_pipeline* p) { pipeline_free(p); }
 
 void* bwtgpu_alloc_host(size_t bytes) {
     void* p = nullptr;

@@ -1,0 +1,102 @@
+// bwt.cpp -- host side of the forward transform: delimiter search, block framing and the
+// `bwt` command-line tool.  All arithmetic happens on the GPU behind include/bwtgpu.h.
+#include "bwt.hpp"
+
+#include <cstdint>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "bwtgpu.h"
+#include "file_processor.hpp"
+#include "slab_runner.hpp"
+
+// Lowest byte value (0-255) that does not occur in the file, or -1 if all 256 occur or the
+// file cannot be opened -- the contract of reference src/bwt.cpp:19-47.  The file is
+// streamed in large slabs; each slab's 256-bit presence mask is computed on the GPU and
+// the masks are OR-ed here.
+int find_unique_char(const char* file_path) {
+    const size_t kSlab = (size_t)64 << 20;
+    FileProcessor processor(file_path, "", kSlab);
+    if (!processor.is_open()) return -1;
+    const size_t slab = processor.input_size() && processor.input_size() < kSlab ? processor.input_size() : kSlab;
+    uint8_t* buf = static_cast<uint8_t*>(bwtgpu_alloc_host(slab));
+    if (!buf) {
+        std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+        return -1;
+    }
+    uint32_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc = 0;
+    while (processor.has_more_data()) {
+        const size_t got = processor.read_bytes(reinterpret_cast<char*>(buf), slab);
+        if (got == 0) break;
+        uint32_t mask[8];
+        rc = bwtgpu_find_unused_byte(buf, got, mask);
+        if (rc < 0 && rc != BWTGPU_ERR_NO_FREE_BYTE) {
+            std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+            bwtgpu_free_host(buf);
+            return -1;
+        }
+        for (int i = 0; i < 8; ++i) seen[i] |= mask[i];
+    }
+    bwtgpu_free_host(buf);
+    processor.close();
+    rc = bwtgpu_lowest_clear_bit(seen);
+    return rc < 0 ? -1 : rc;
+}
+
+std::string bwt_forward(const std::string& input, char delimiter) {
+    std::string out(input.size() + 1, delimiter);
+    if (input.empty()) return out;
+    const int rc = bwtgpu_forward_batch(0, reinterpret_cast<const uint8_t*>(input.data()), input.size(), input.size(),
+                                        static_cast<uint8_t>(delimiter), reinterpret_cast<uint8_t*>(&out[0]));
+    if (rc != BWTGPU_OK) {
+        std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+        return std::string();
+    }
+    return out;
+}
+
+int bwt_forward_process_file(const char* input_file, const char* output_file, size_t block_size) {
+    const int delimiter_byte = find_unique_char(input_file);
+    if (delimiter_byte == -1) {
+        std::cerr << "Error: Cannot find a unique delimiter (all 256 byte values appear in file)" << std::endl;
+        return 1;
+    }
+    const char delimiter = static_cast<char>(delimiter_byte);
+
+    FileProcessor processor(input_file, output_file, block_size);
+    if (!processor.is_open()) return 1;
+    if (block_size == 0) {
+        std::cerr << "Error: Block size must be greater than 0" << std::endl;
+        return 1;
+    }
+    // header: the delimiter, then the transformed blocks in input order
+    if (!processor.write_bytes(&delimiter, 1)) {
+        std::cerr << "Error: short write to the output file" << std::endl;
+        return 1;
+    }
+    const int rc = bwt_host::run_slabs(processor, BWTGPU_FORWARD, block_size, static_cast<unsigned char>(delimiter),
+                                       processor.input_size());
+    processor.close();
+    return rc;
+}
+
+#ifndef BUILD_TESTS
+int main(int argc, char* argv[]) {
+    if (argc < 3 || argc > 4) {
+        std::cerr << "Usage: " << argv[0] << " <input_file> <output_file> [block_size]" << std::endl;
+        std::cerr << "  block_size: size of each block in bytes (default: 128)" << std::endl;
+        return 1;
+    }
+    size_t block_size = 128;
+    if (argc == 4) {
+        block_size = std::stoul(argv[3]);
+        if (block_size == 0) {
+            std::cerr << "Error: Block size must be greater than 0" << std::endl;
+            return 1;
+        }
+    }
+    return bwt_forward_process_file(argv[1], argv[2], block_size);
+}
+#endif  // BUILD_TESTS

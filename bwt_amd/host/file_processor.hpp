@@ -1,0 +1,58 @@
+// file_processor.hpp -- block-granular binary file reader/writer.
+//
+// Public interface and observable behaviour follow the reference's
+// src/file_processor.hpp:9-46 / src/file_processor.cpp:4-83 (same constructor, same
+// method names and results, same "Error: Could not open ..." messages, an empty output
+// path meaning read-only).  Two bulk methods are added for the slab pipeline, which
+// moves many blocks per call straight into and out of pinned host memory.
+#ifndef FILE_PROCESSOR_HPP
+#define FILE_PROCESSOR_HPP
+
+#include <cstddef>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+class FileProcessor {
+public:
+    FileProcessor(const std::string& input_path, const std::string& output_path, size_t block_size);
+    ~FileProcessor();
+    FileProcessor(const FileProcessor&) = delete;
+    FileProcessor& operator=(const FileProcessor&) = delete;
+
+    // True if the input is open (and, when an output path was given, the output too).
+    bool is_open() const;
+    // True until a read has hit the end of the input (like std::ifstream::good(): a file
+    // whose size is an exact multiple of the block size needs one more, empty, read).
+    bool has_more_data() const;
+    // Next block: block_size bytes, fewer at the end of the file, "" when nothing is left.
+    std::string read_chunk();
+    // One byte; false at end of file.
+    bool read_char(char& c);
+    // Appends a block to the output (no-op without an output file or for an empty chunk).
+    void write_chunk(const std::string& chunk);
+    void close();
+    size_t get_block_size() const;
+
+    // ---- additions (not in the reference) ----
+    // Reads up to `max_bytes` into `dst`; returns the count (0 at end of file).
+    size_t read_bytes(char* dst, size_t max_bytes);
+    // Appends `n` bytes to the output; false if the write failed.
+    bool write_bytes(const char* src, size_t n);
+    // Size of the input file in bytes (0 if it is not a regular file: see input_is_regular()).
+    size_t input_size() const;
+    bool input_is_regular() const;
+
+private:
+    std::FILE* in_ = nullptr;
+    std::FILE* out_ = nullptr;
+    size_t block_size_;
+    bool good_ = false;  // no read has come up short yet
+    size_t input_size_ = 0;
+    bool regular_ = false;
+    std::vector<char> scratch_;
+    mutable std::mutex mutex_;  // one lock for both streams, as in the reference
+};
+
+#endif  // FILE_PROCESSOR_HPP

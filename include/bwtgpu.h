@@ -100,6 +100,29 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total_le
 int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total_len_with_delims,
                          size_t block_size, uint8_t delimiter, uint8_t* out, size_t* out_len);
 
+/* ---- slab pipeline: replaces the reader -> BlockingQueue -> workers -> ReorderBuffer ->
+ *      writer threads of reference src/bwt.cpp:183-233 (and the serial read/transform/write
+ *      loop of src/inverse_bwt.cpp:85-95).  The caller fills a pinned input slab with whole
+ *      blocks, submits it, and later collects the transformed slab; every slot owns a HIP
+ *      stream, so the upload of slab k+1, the kernels of slab k and the download of slab k-1
+ *      overlap.  Order is implicit: block i of a slab lands at its closed-form offset, and
+ *      the caller collects slots in submission order. -------------------------------------- */
+typedef struct bwtgpu_pipeline bwtgpu_pipeline;
+#define BWTGPU_FORWARD 0
+#define BWTGPU_INVERSE 1
+/* `slab_blocks` blocks per slab, `depth` slots in flight (>= 1).  NULL on error. */
+bwtgpu_pipeline* bwtgpu_pipeline_create(int device, int direction, size_t block_size, size_t slab_blocks,
+                                        int depth);
+/* Pinned host buffer of slot `slot`; capacity bwtgpu_pipeline_input_capacity() bytes. */
+uint8_t* bwtgpu_pipeline_input(bwtgpu_pipeline* p, int slot);
+size_t bwtgpu_pipeline_input_capacity(const bwtgpu_pipeline* p);
+/* Enqueues upload + transform + download of the first `bytes` bytes of the slot's input. */
+int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter);
+/* Blocks until the slot is done; *out / *out_bytes describe its pinned result, valid until
+ * the slot is submitted again.  Inverse results are already compacted. */
+int bwtgpu_pipeline_collect(bwtgpu_pipeline* p, int slot, const uint8_t** out, size_t* out_bytes);
+void bwtgpu_pipeline_destroy(bwtgpu_pipeline* p);
+
 /* ---- delimiter search: replaces reference src/bwt.cpp:19-47 (find_unique_char) --
  * presence[8] is a 256-bit "byte value occurs" mask (bit v%32 of word v/32).  The
  * device variant ORs into d_presence (zero it first); callers holding several

@@ -1,0 +1,106 @@
+"""The C++ host layer (reference-compatible API + CLIs) on the GPU: runs the C++ test
+programs and checks the command-line tools byte-for-byte against the golden vectors."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from conftest import CORPUS, ROOT
+
+pytestmark = pytest.mark.gpu
+BUILD = os.path.join(ROOT, "build")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def binaries():
+    need = ["bwt", "inverse_bwt", "test_small", "test_medium", "performance"]
+    if not all(os.path.exists(os.path.join(BUILD, n)) for n in need):
+        subprocess.check_call(["make", "-C", ROOT, "-j8", "all"])
+    yield
+
+
+def run(args, **kw):
+    return subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_cpp_known_answers():
+    r = run([os.path.join(BUILD, "test_small")])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "All tests passed!" in r.stdout and "[FAIL]" not in r.stdout
+
+
+def test_cpp_file_round_trips():
+    r = run([os.path.join(BUILD, "test_medium")])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("[PASS]") == 55  # 11 files x 5 block sizes (kennedy.xls: expected rejection)
+
+
+def test_cli_matches_golden(corpus_golden, tmp_path):
+    rows = [r for r in corpus_golden["files"] if r["file"] in ("alice29.txt", "ptt5", "sum", "kennedy.xls")
+            and r["block_size"] in (4096, 131072, 1048576)]
+    assert rows
+    for row in rows:
+        src = os.path.join(CORPUS, row["file"])
+        f, b = str(tmp_path / "f.bwt"), str(tmp_path / "f.out")
+        r = run([os.path.join(BUILD, "bwt"), src, f, str(row["block_size"])])
+        assert r.returncode == row["rc"], (row, r.stderr)
+        if row["rc"]:
+            assert "Cannot find a unique delimiter" in r.stderr
+            continue
+        assert hashlib.sha256(open(f, "rb").read()).hexdigest() == row["sha256"], row
+        r = run([os.path.join(BUILD, "inverse_bwt"), f, b, str(row["block_size"])])
+        assert r.returncode == 0, r.stderr
+        assert open(b, "rb").read() == open(src, "rb").read()
+
+
+def test_cli_contract(tmp_path):
+    bwt, inv = os.path.join(BUILD, "bwt"), os.path.join(BUILD, "inverse_bwt")
+    for exe in (bwt, inv):
+        r = run([exe])
+        assert r.returncode == 1 and "Usage:" in r.stderr
+        r = run([exe, "a", "b", "0"])
+        assert r.returncode == 1 and "Block size must be greater than 0" in r.stderr
+        r = run([exe, str(tmp_path / "missing"), str(tmp_path / "o")])
+        assert r.returncode == 1 and "Could not open input file" in r.stderr
+    # default block size is 128 bytes (reference src/bwt.cpp:249, src/inverse_bwt.cpp:111)
+    src = os.path.join(CORPUS, "grammar.lsp")
+    f, b = str(tmp_path / "g.bwt"), str(tmp_path / "g.out")
+    assert run([bwt, src, f]).returncode == 0
+    n = os.path.getsize(src)
+    assert os.path.getsize(f) == n + 1 + (n + 127) // 128
+    assert run([inv, f, b]).returncode == 0
+    assert open(b, "rb").read() == open(src, "rb").read()
+    # empty file -> 1-byte output (delimiter 0x00); inverting it gives an empty file
+    e, ef, eb = str(tmp_path / "e"), str(tmp_path / "e.bwt"), str(tmp_path / "e.out")
+    open(e, "wb").close()
+    assert run([bwt, e, ef, "1024"]).returncode == 0
+    assert open(ef, "rb").read() == b"\x00"
+    assert run([inv, ef, eb, "1024"]).returncode == 0
+    assert os.path.getsize(eb) == 0
+    # an empty .bwt file is an error (reference src/inverse_bwt.cpp:78-82)
+    r = run([inv, e, eb, "1024"])
+    assert r.returncode == 1 and "Empty input file" in r.stderr
+
+
+def test_two_slab_pipeline_depth(tmp_path):
+    """A file larger than one slab exercises slot reuse and in-order collection."""
+    import numpy as np
+
+    from bwt_amd import synth
+    import oracle
+
+    data = synth.generate("acgt", 5, 0, 40 * (1 << 20) + 12345)  # 512-byte blocks: 16 MiB slabs -> 3 slabs
+    src, f, b = str(tmp_path / "big"), str(tmp_path / "big.bwt"), str(tmp_path / "big.out")
+    data.tofile(src)
+    assert run([os.path.join(BUILD, "bwt"), src, f, "512"]).returncode == 0
+    out = np.fromfile(f, dtype=np.uint8)
+    assert out.size == data.size + 1 + (data.size + 511) // 512
+    # spot-check blocks from every slab against the oracle
+    orc = oracle.oracle()
+    for blk in (0, 1, 32767, 32768, 40000, 70000, (data.size - 1) // 512):
+        want = orc.forward(data[blk * 512:(blk + 1) * 512].tobytes(), int(out[0]))
+        got = out[1 + blk * 513:1 + blk * 513 + len(want)].tobytes()
+        assert got == want, blk
+    assert run([os.path.join(BUILD, "inverse_bwt"), f, b, "512"]).returncode == 0
+    assert np.array_equal(np.fromfile(b, dtype=np.uint8), data)
