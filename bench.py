@@ -183,6 +183,11 @@ def main() -> None:
     roundtrip_ok = bool(torch.equal(d_in, d_back))
     lens_ok = bool((d_lens[:-1] == bs).all().item()) and int(d_lens[-1].item()) == nbytes - (nblocks - 1) * bs
     status = d_ws_f[:8].cpu().numpy().view("uint32")  # [1] = forward kernel error flags
+    ph = d_ws_f[64:64 + 80].cpu().numpy().view("uint64").astype(float)
+    names = ["census", "keys0", "sort0", "rerank0", "keys", "sort", "rerank", "gather"]
+    tot = max(1.0, float(ph[:8].sum()))
+    phase_share = {k: round(float(v) / tot, 4) for k, v in zip(names, ph[:8])}
+    phase_share["later_rounds_per_block"] = round(float(ph[9]) / max(1.0, float(ph[8])), 3)
     ok = torch.tensor([int(roundtrip_ok and lens_ok and int(status[1]) == 0)], device=dev)
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -243,6 +248,7 @@ def main() -> None:
             "roundtrip_pct_of_hbm_roofline": 100.0 * (4 * nbytes + 2 * nblocks) * world / step_s / (HBM_PEAK * world),
             "roundtrip_verified": all_ok,
             "kernel_status": int(status[1]),
+            "forward_phase_share": phase_share,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

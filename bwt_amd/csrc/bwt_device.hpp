@@ -25,16 +25,26 @@ __device__ __host__ __forceinline__ int bit_length(uint32_t v) {
 }
 
 // Lanes of this wavefront whose `valid` digit equals mine (bit i set <=> lane i is a
-// peer).  One ballot per digit bit: the wave64 form of a match-any.
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool valid) {
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < nbits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
+// peer).  One ballot per digit bit: the wave64 form of a match-any.  BITS is the digit
+// width the caller guarantees (higher bits of d must be zero).
+template <int BITS>
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+    const uint64_t vm = __ballot(valid);
+    uint32_t lo = (uint32_t)vm, hi = (uint32_t)(vm >> 32);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // all ones when my bit b is set
+        const uint64_t bal = __ballot(x != 0u);
+        lo &= ~((uint32_t)bal ^ x);  // keep lanes whose bit equals mine
+        hi &= ~((uint32_t)(bal >> 32) ^ x);
     }
-    return peers;
+    return ((uint64_t)hi << 32) | lo;
 }
+
+// Keeps the compiler from moving memory operations across this point (used where lanes of
+// one wave hand values to each other through LDS and the order of a read and a later write
+// matters).
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 
 // Exclusive prefix sum of one value per thread over the workgroup; `total` receives
 // the workgroup sum.  s_wsum needs NT/64 words.  Contains two barriers.

@@ -9,17 +9,21 @@
 // Algorithm (per block, n = len + 1 symbols including the appended delimiter)
 //   0. census: which byte values occur -> dense order-preserving codes 1..sigma
 //      (0 is reserved for "past the end"), sbits = bits per code.
-//   1. round 0: element i = (first m0 codes of suffix i, packed) << ibits | i;
-//      LSD radix sort of all n elements on the packed key.
+//   1. round 0: element i = (first m0 codes of suffix i, packed) << ibits | i, built by
+//      a rolling window over the input bytes; LSD radix sort of all n elements on the key.
+//      The first pass needs no stability, so the keys are generated straight into it and
+//      never stored unsorted.
 //   2. rerank: equal-key runs are groups; rank[i] = position of its group's first
 //      element (so a final rank IS the suffix-array position); suffixes alone in
 //      their group are finished and leave the working set (wave-ballot + prefix-
 //      count compaction); survivors get a dense group id g.
 //   3. round r >= 1 (prefix length h doubles): element = g | rank[i+h]+1 | i for the
-//      survivors only; LSD radix sort on (g, rank[i+h]); rerank inside the old
+//      survivors only; LSD radix sort on (g, rank[i+h]+1); rerank inside the old
 //      groups; repeat until no survivor is left.
-//   4. gather: out[rank[i]] = s[i-1] (the delimiter for i == 0, which lands on the
-//      row of suffix 0 -- the block's primary index is that row).
+//   4. output: a suffix that becomes alone in its group is finished; its rank is its row and
+//      it stores the byte that precedes it there (the delimiter for suffix 0 -- that row is
+//      the block's primary index).  Round-0 finishers carry that byte in their element and
+//      store it coalesced; later finishers fetch it from the text.
 //
 // Every array of a block lives in a per-workgroup slice of HBM scratch (two u64
 // element buffers and one u32 rank array); LDS holds the per-wave digit histograms.
@@ -38,47 +42,74 @@ struct FwdArgs {
     uint32_t delim;
     uint8_t* ws;          // workgroup w owns ws + w*ws_stride
     uint64_t ws_stride;
-    uint32_t* queue;      // [0] next block index to hand out, [1] error flags
+    uint32_t* queue;      // [0] next block index to hand out, [1] error flags, [16..] phase clocks
 };
 
 constexpr uint32_t kErrNotConverged = 1u;
 constexpr uint32_t kErrBounds = 2u;
+constexpr int kMaxM0 = 17;    // symbols per round-0 key (bounded by the 24-byte rolling window)
+constexpr int kRun = 8;       // consecutive positions one lane rolls through in round 0
+constexpr int kTile = kRun * kWave;  // positions per wave iteration in round 0
+
+// Per-phase time accounting (100 MHz constant clock), summed over workgroups into
+// queue[16..] as u64: 0 census, 1 round-0 digit count, 2 round-0 sort, 3 round-0 rerank,
+// 4 later key builds, 5 later sorts, 6 later reranks, 7 full-rank rebuilds, 8 blocks, 9 later rounds.
+struct PhaseClock {
+    unsigned long long t;
+    unsigned long long* acc;
+    __device__ __forceinline__ void start(uint32_t* queue) {
+        acc = reinterpret_cast<unsigned long long*>(queue + 16);
+        t = wall_clock64();
+    }
+    __device__ __forceinline__ void lap(int phase) {
+        if (threadIdx.x == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(&acc[phase], now - t);
+            t = now;
+        }
+    }
+    __device__ __forceinline__ void count(int slot, unsigned long long v) {
+        if (threadIdx.x == 0) atomicAdd(&acc[slot], v);
+    }
+};
 
 template <int NT>
 struct FwdShared {
     static constexpr int W = NT / kWave;
-    uint32_t histA[W * kBins];
-    uint32_t histB[W * kBins];
-    uint32_t sym[256];
+    uint32_t hist[2][W * kBins];  // per-wave digit counts / scatter offsets, double buffered
+    uint32_t sym[256];            // byte value -> code
     uint32_t wsum[W];
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
     uint32_t blk;
 };
 
 template <int NT>
-__device__ __forceinline__ void zero_hist(uint32_t* hist) {
+__device__ __forceinline__ void zero_hist(FwdShared<NT>& sh, int sel) {
     constexpr int W = NT / kWave;
-    for (int i = threadIdx.x; i < W * kBins; i += NT) hist[i] = 0;
+    for (int i = threadIdx.x; i < W * kBins; i += NT) sh.hist[sel][i] = 0;
 }
 
 // Turns per-wave digit counts hist[w][d] into scatter offsets: exclusive prefix sum in
-// (digit major, wave minor) order, which is what makes the pass stable.
+// (digit major, wave minor) order, which is what makes a pass stable.
 template <int NT>
-__device__ __forceinline__ void scan_hist(uint32_t* hist, uint32_t* s_wsum) {
+__device__ __forceinline__ void scan_hist(FwdShared<NT>& sh, int sel) {
     constexpr int W = NT / kWave;
     constexpr int PER = (kBins + NT - 1) / NT;  // bins per thread
+    uint32_t* hist = sh.hist[sel];
     const int first = threadIdx.x * PER;
     uint32_t tot = 0;
     if (first < kBins) {
 #pragma unroll
         for (int j = 0; j < PER; ++j)
+#pragma unroll
             for (int w = 0; w < W; ++w) tot += hist[w * kBins + first + j];
     }
     uint32_t total;
-    uint32_t run = block_exclusive_scan<NT>(tot, s_wsum, total);
+    uint32_t run = block_exclusive_scan<NT>(tot, sh.wsum, total);
     if (first < kBins) {
 #pragma unroll
         for (int j = 0; j < PER; ++j)
+#pragma unroll
             for (int w = 0; w < W; ++w) {
                 const uint32_t v = hist[w * kBins + first + j];
                 hist[w * kBins + first + j] = run;
@@ -88,66 +119,194 @@ __device__ __forceinline__ void scan_hist(uint32_t* hist, uint32_t* s_wsum) {
     __syncthreads();
 }
 
-// One stable LSD pass: scatter src[0..m) to dst by digit (e >> shift) & mask, and count
-// the NEXT pass's digit per destination wave chunk on the fly (so every pass reads and
-// writes each element exactly once).
-template <int NT>
+// Places one element per lane: stable rank among the lanes of this wave vector that hold
+// the same digit (ballot match), next free slot of the digit from the wave's LDS offsets,
+// scatter to dst, and the NEXT pass's digit counted per destination wave chunk.
+template <int BITS>
+__device__ __forceinline__ void rank_and_scatter(uint64_t e, bool valid, uint32_t d, uint32_t* myoff,
+                                                 uint64_t* __restrict__ dst, uint32_t m, bool has_next,
+                                                 int nshift, uint32_t nmask, const Chunking& ck,
+                                                 uint32_t* nhist, uint32_t* err) {
+    const uint64_t peers = match_digit<BITS>(d, valid);
+    const uint32_t rk = __popcll(peers & lanemask_lt());
+    const uint32_t b0 = myoff[valid ? d : 0u];
+    compiler_fence();  // every lane has read its offset before the leaders advance it
+    if (valid && rk == 0) myoff[d] = b0 + (uint32_t)__popcll(peers);
+    compiler_fence();
+    if (valid) {
+        const uint32_t pos = b0 + rk;
+        if (pos < m) {
+            dst[pos] = e;
+            if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + ((uint32_t)(e >> nshift) & nmask)], 1u);
+        } else {
+            atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
+        }
+    }
+}
+
+// One stable LSD pass over src[0..m): each wave walks its contiguous chunk one 64-element
+// vector at a time, four vectors prefetched ahead.
+template <int NT, int BITS>
 __device__ __forceinline__ void radix_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
-                                           uint32_t m, const Chunking& ck, int shift, int bits,
-                                           bool has_next, int nshift, int nbits, uint32_t* off,
-                                           uint32_t* nhist, uint32_t* err) {
+                                           uint32_t m, const Chunking& ck, int shift, int bits, bool has_next,
+                                           int nshift, int nbits, FwdShared<NT>& sh, int sel, uint32_t* err) {
     const int lane = lane_id(), w = wave_id();
     const uint32_t lo = (uint32_t)w * ck.chunk;
     const uint32_t hi = min(lo + ck.chunk, m);
-    volatile uint32_t* myoff = off + w * kBins;
-    const uint32_t mask = (1u << bits) - 1u, nmask = (1u << nbits) - 1u;
-    const uint64_t lt = lanemask_lt();
-    for (uint32_t base = lo; base < hi; base += kWave) {
-        const uint32_t k = base + lane;
-        const bool valid = k < hi;
-        const uint64_t e = valid ? src[k] : 0ull;
-        const uint32_t d = (uint32_t)(e >> shift) & mask;
-        const uint64_t peers = match_digit(d, bits, valid);
-        const uint32_t rk = __popcll(peers & lt);
-        const uint32_t cnt = __popcll(peers);
-        uint32_t b0 = 0;
-        if (valid) b0 = myoff[d];
-        if (valid && rk == 0) myoff[d] = b0 + cnt;
-        if (valid) {
-            const uint32_t pos = b0 + rk;
-            if (pos < m) {
-                dst[pos] = e;
-                if (has_next) {
-                    const uint32_t nd = (uint32_t)(e >> nshift) & nmask;
-                    atomicAdd(&nhist[ck.wave_of(pos) * kBins + nd], 1u);
-                }
-            } else {
-                atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
+    uint32_t* myoff = sh.hist[sel] + w * kBins;
+    uint32_t* nhist = sh.hist[sel ^ 1];
+    const uint32_t mask = (1u << bits) - 1u, nmask = (1u << nbits) - 1u;  // bits <= BITS
+    // four vectors in flight per wave: each register is refilled right after it is consumed
+    constexpr int D = 4;
+    uint64_t e[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        e[j] = 0;
+        if (lo + j * kWave + lane < hi) e[j] = src[lo + j * kWave + lane];
+    }
+    for (uint32_t base = lo; base < hi; base += D * kWave) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t k = base + j * kWave + lane;
+            if (base + j * kWave < hi) {  // wave-uniform
+                const uint64_t cur = e[j];
+                e[j] = 0;
+                if (k + D * kWave < hi) e[j] = src[k + D * kWave];
+                rank_and_scatter<BITS>(cur, k < hi, (uint32_t)(cur >> shift) & mask, myoff, dst, m, has_next, nshift,
+                                       nmask, ck, nhist, err);
             }
         }
     }
 }
 
-// Sorts a[0..m) by the K key bits starting at bit key_shift.  On entry hA holds the
-// per-wave counts of pass 0's digit (chunked by Chunking(m)).  Returns the buffer that
-// holds the sorted elements (a or b).
+// Sorts a[0..m) by the plan's key bits starting at bit key_shift.  On entry hist[sel] holds
+// the per-wave counts of pass `first_pass`'s digit (chunked by Chunking(m)); passes before
+// first_pass have been done by the caller.  Returns the buffer holding the sorted elements.
 template <int NT>
 __device__ __forceinline__ uint64_t* radix_sort(uint64_t* a, uint64_t* b, uint32_t m, int key_shift,
-                                                const DigitPlan& plan, uint32_t* hA, uint32_t* hB,
-                                                uint32_t* s_wsum, uint32_t* err) {
+                                                const DigitPlan& plan, int first_pass, FwdShared<NT>& sh,
+                                                int sel, uint32_t* err) {
     Chunking ck;
     ck.init(m, NT / kWave);
-    for (int p = 0; p < plan.P; ++p) {
+    for (int p = first_pass; p < plan.P; ++p) {
         const bool has_next = p + 1 < plan.P;
-        if (has_next) zero_hist<NT>(hB);
-        scan_hist<NT>(hA, s_wsum);  // its barriers also publish the zeroed hB
-        radix_pass<NT>(a, b, m, ck, key_shift + plan.shift(p), plan.bits(p), has_next,
-                       key_shift + plan.shift(has_next ? p + 1 : p), plan.bits(has_next ? p + 1 : p), hA, hB, err);
+        if (has_next) zero_hist<NT>(sh, sel ^ 1);
+        scan_hist<NT>(sh, sel);  // its barriers also publish the zeroed next histogram
+        const int shift = key_shift + plan.shift(p);
+        const int nshift = key_shift + plan.shift(has_next ? p + 1 : p);
+        const int nbits = plan.bits(has_next ? p + 1 : p);
+        const int bits = plan.bits(p);
+        // the digit is at most `bits` wide, so matching on more bits is exact (they are zero)
+        if (bits > 8) radix_pass<NT, 9>(a, b, m, ck, shift, bits, has_next, nshift, nbits, sh, sel, err);
+        else if (bits > 6) radix_pass<NT, 8>(a, b, m, ck, shift, bits, has_next, nshift, nbits, sh, sel, err);
+        else radix_pass<NT, 6>(a, b, m, ck, shift, bits, has_next, nshift, nbits, sh, sel, err);
         __syncthreads();
         uint64_t* t = a; a = b; b = t;
-        uint32_t* th = hA; hA = hB; hB = th;
+        sel ^= 1;
     }
     return a;
+}
+
+// ---- round 0: rolling packed keys -------------------------------------------------------------
+struct Round0 {
+    const uint8_t* s;      // block text (len bytes), the delimiter is virtual at position len
+    const uint8_t* g_lo;   // readable byte range of the whole batch buffer: [g_lo, g_hi)
+    const uint8_t* g_hi;
+    uint32_t len, n;
+    uint32_t dcode;        // code of the delimiter
+    uint32_t delim;        // the delimiter byte itself
+    int m0, sbits, ibits;
+    uint64_t kmask;        // m0*sbits low bits
+};
+
+__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* p, const uint8_t* g_lo, const uint8_t* g_hi) {
+    if (p >= g_lo && p + 4 <= g_hi) return *reinterpret_cast<const uint32_t*>(p);
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (p + j >= g_lo && p + j < g_hi) v |= (uint32_t)p[j] << (8 * j);
+    return v;
+}
+
+// Round-0 element: key << (ibits + 8) | preceding byte << ibits | position.  Carrying the byte
+// that precedes the suffix through the sort lets every suffix that is already unique after
+// round 0 emit its output byte with a coalesced store (no gather, no rank array).
+// MODE 0: count pass 0's digit of every element into hist[sel] (per wave).
+// MODE 1: generate the elements again and run pass 0 on them (rank + scatter into dst).
+// Lane l of a wave tile rolls through positions q0 .. q0+7 (q0 = tile + 8 l): it reads the 24
+// bytes that start at q0 + m0 - 17, pushes one symbol code per step into a shift register
+// and, from step 16 on, the register holds the key of position q0 + (step - 16).
+template <int NT, int MODE>
+__device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& plan, uint64_t* __restrict__ dst,
+                                             FwdShared<NT>& sh, int sel, uint32_t* err) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    uint32_t chunk0 = (r.n + (uint32_t)W - 1u) / (uint32_t)W;
+    chunk0 = (chunk0 + (uint32_t)kTile - 1u) / (uint32_t)kTile * (uint32_t)kTile;
+    const uint32_t lo = (uint32_t)w * chunk0;
+    const uint32_t hi = min(lo + chunk0, r.n);
+    Chunking ck;
+    ck.init(r.n, W);
+    uint32_t* myoff = sh.hist[sel] + w * kBins;
+    uint32_t* nhist = sh.hist[sel ^ 1];
+    const uint32_t dmask = (1u << plan.bits(0)) - 1u;
+    const bool has_next = plan.P > 1;
+    const int kshift = r.ibits + 8;
+    const int nshift = kshift + plan.shift(has_next ? 1 : 0);
+    const uint32_t nmask = (1u << plan.bits(has_next ? 1 : 0)) - 1u;
+    const int lead = kMaxM0 - r.m0;  // steps whose symbols would be shifted out anyway
+    for (uint32_t tile = lo; tile < hi; tile += kTile) {
+        const uint32_t q0 = tile + (uint32_t)(kRun * lane);
+        const int64_t wstart = (int64_t)q0 + r.m0 - kMaxM0;  // text position of window byte 0
+        // 7 aligned dwords cover the 24 window bytes at any alignment
+        const uint8_t* wp = r.s + wstart;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(wp) & 3u);
+        const uint8_t* ap = wp - mis;
+        uint32_t raw[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) raw[j] = load_dword_guarded(ap + 4 * j, r.g_lo, r.g_hi);
+        uint32_t win[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) win[j] = __builtin_amdgcn_alignbyte(raw[j + 1], raw[j], mis);
+        // the 8 bytes that precede positions q0 .. q0+7 (text positions q0-1 .. q0+6)
+        uint32_t prevw[2] = {0u, 0u};
+        if (MODE == 1) {
+            const uint8_t* pp = r.s + (int64_t)q0 - 1;
+            const uint32_t pmis = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3u);
+            const uint8_t* pa = pp - pmis;
+            const uint32_t p0 = load_dword_guarded(pa, r.g_lo, r.g_hi);
+            const uint32_t p1 = load_dword_guarded(pa + 4, r.g_lo, r.g_hi);
+            const uint32_t p2 = load_dword_guarded(pa + 8, r.g_lo, r.g_hi);
+            prevw[0] = __builtin_amdgcn_alignbyte(p1, p0, pmis);
+            prevw[1] = __builtin_amdgcn_alignbyte(p2, p1, pmis);
+        }
+        uint64_t key = 0;
+#pragma unroll
+        for (int t = 0; t < 16 + kRun; ++t) {
+            if (t >= lead) {  // wave-uniform
+                const uint32_t pos = q0 + (uint32_t)(t - lead);  // = wstart + t, never negative here
+                const uint32_t byte = (win[t >> 2] >> (8 * (t & 3))) & 255u;
+                uint32_t c = sh.sym[byte];
+                if (pos >= r.len) c = (pos == r.len) ? r.dcode : 0u;
+                key = ((key << r.sbits) | c) & r.kmask;
+            }
+            if (t >= 16) {
+                const uint32_t pe = q0 + (uint32_t)(t - 16);
+                const bool valid = pe < hi;
+                const uint32_t d = (uint32_t)key & dmask;
+                if (MODE == 0) {
+                    if (valid) atomicAdd(&myoff[d], 1u);
+                } else {
+                    const int j = t - 16;
+                    uint32_t prev = (prevw[j >> 2] >> (8 * (j & 3))) & 255u;
+                    if (pe == 0) prev = r.delim;  // the row of suffix 0 carries the delimiter (src/bwt.cpp:115-116)
+                    const uint64_t e = (key << kshift) | ((uint64_t)prev << r.ibits) | pe;
+                    rank_and_scatter<kMaxDigitBits>(e, valid, d, myoff, dst, r.n, has_next, nshift, nmask, ck, nhist,
+                                                    err);
+                }
+            }
+        }
+    }
 }
 
 struct RunFlags {
@@ -158,7 +317,7 @@ struct RunFlags {
 // Flags of sorted position k: head/tail of its equal-key run, head of its old group.
 template <bool ROUND0>
 __device__ __forceinline__ RunFlags run_flags(const uint64_t* __restrict__ cur, uint32_t k, uint32_t hi,
-                                              uint32_t m, int ibits, int gshift) {
+                                              uint32_t m, int kshift, int gshift) {
     RunFlags f;
     f.valid = k < hi;
     uint64_t e = 0, ep = 0, en = 0;
@@ -167,21 +326,41 @@ __device__ __forceinline__ RunFlags run_flags(const uint64_t* __restrict__ cur, 
         if (k > 0) ep = cur[k - 1];
         if (k + 1 < m) en = cur[k + 1];
     }
-    const uint64_t key = e >> ibits;
-    f.head = f.valid && (k == 0 || (ep >> ibits) != key);
-    f.tail = f.valid && (k + 1 == m || (en >> ibits) != key);
+    const uint64_t key = e >> kshift;
+    f.head = f.valid && (k == 0 || (ep >> kshift) != key);
+    f.tail = f.valid && (k + 1 == m || (en >> kshift) != key);
     f.ghead = f.valid && (k == 0 || (!ROUND0 && (ep >> gshift) != (e >> gshift)));
     f.e = e;
     return f;
 }
 
-// After a sort: assign positional ranks, drop finished suffixes, emit the survivors
-// (dense group id << gshift | index) to nxt.  Returns survivors in m_next and their
+// What rerank needs to know about the block besides the sorted elements.
+struct BlockIO {
+    const uint8_t* s;   // block text
+    uint8_t* out;       // block output (n bytes)
+    uint32_t n;
+    uint32_t delim;
+};
+
+// After a sort: find the equal-key runs (groups), give every suffix the position of its
+// group's first element as rank, let suffixes that are alone in their group emit their
+// output byte and leave the working set, and compact the survivors
+// (dense group id << gshift | index) into nxt.  Returns the survivor count in m_next and their
 // group count in g_next.
+//
+// ROUND0: cur holds all n round-0 elements.  Finished suffixes store their byte (carried in the
+// element) at their sorted position -- a coalesced store.  When few suffixes survive
+// (<= n/16, decided from the counting phase) the rank array is written for the survivors only
+// (`full_out` = false): the next round then ranks suffix i+h by binary search in cur
+// instead of reading rank[i+h].  `force_full` makes it write all ranks.
+// Later rounds: cur holds the m survivors sorted by (group, rank of the suffix h further on);
+// ranks move up by the offset inside the old group; newly finished suffixes fetch their
+// preceding byte from the text.
 template <int NT, bool ROUND0>
 __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_t* __restrict__ nxt,
-                                       uint32_t* __restrict__ rank, uint32_t m, int ibits, int gshift,
-                                       FwdShared<NT>& sh, uint32_t& m_next, uint32_t& g_next) {
+                                       uint32_t* __restrict__ rank, const BlockIO& io, uint32_t m, int ibits,
+                                       int kshift, int gshift, bool force_full, FwdShared<NT>& sh,
+                                       uint32_t& m_next, uint32_t& g_next, bool& full_out) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
     Chunking ck;
@@ -195,7 +374,7 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
     {
         uint32_t cA = 0, cG = 0, lH = 0, lG = 0;
         for (uint32_t base = lo; base < hi; base += kWave) {
-            const RunFlags f = run_flags<ROUND0>(cur, base + lane, hi, m, ibits, gshift);
+            const RunFlags f = run_flags<ROUND0>(cur, base + lane, hi, m, kshift, gshift);
             const uint64_t H = __ballot(f.head), G = __ballot(f.ghead);
             cA += __popcll(__ballot(f.valid && !(f.head && f.tail)));
             cG += __popcll(__ballot(f.head && !f.tail));
@@ -224,24 +403,29 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
         totA += a;
         totG += g;
     }
-    // phase C: ranks + compaction
+    const bool full = !ROUND0 || force_full || totA > m / 16u;
+    // phase C: ranks, output bytes of finished suffixes, compaction of the rest
     for (uint32_t base = lo; base < hi; base += kWave) {
-        const RunFlags f = run_flags<ROUND0>(cur, base + lane, hi, m, ibits, gshift);
+        const RunFlags f = run_flags<ROUND0>(cur, base + lane, hi, m, kshift, gshift);
         const uint64_t H = __ballot(f.head), G = __ballot(f.ghead);
         const uint64_t hm = H & le, gm = G & le;
         const uint32_t khead = hm ? base + 63u - (uint32_t)__clzll(hm) : carryH;
         const uint32_t kg = gm ? base + 63u - (uint32_t)__clzll(gm) : carryG;
         if (H) carryH = base + 63u - (uint32_t)__clzll(H);
         if (G) carryG = base + 63u - (uint32_t)__clzll(G);
-        const bool act = f.valid && !(f.head && f.tail);
+        const bool single = f.head && f.tail;
+        const bool act = f.valid && !single;
         const uint64_t A = __ballot(act), NS = __ballot(f.head && !f.tail);
         const uint32_t idx = (uint32_t)(f.e & imask);
-        if (f.valid) {
-            if (ROUND0) {
-                rank[idx] = khead;
-            } else {
-                const uint32_t delta = khead - kg;
-                if (delta) rank[idx] += delta;
+        if (ROUND0) {
+            if (f.valid && (full || act)) rank[idx] = khead;
+            if (single) io.out[base + lane] = (uint8_t)(f.e >> ibits);
+        } else if (f.valid) {
+            const uint32_t delta = khead - kg;
+            if (delta || single) {
+                const uint32_t rn = rank[idx] + delta;
+                if (delta) rank[idx] = rn;
+                if (single && rn < io.n) io.out[rn] = idx ? io.s[idx - 1] : (uint8_t)io.delim;
             }
         }
         if (act) {
@@ -254,20 +438,46 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
     }
     m_next = totA;
     g_next = totG;
+    full_out = full;
     __syncthreads();
+}
+
+// Rank of suffix j by its first m0 symbols = number of round-0 elements with a smaller key:
+// binary search in the sorted round-0 array (used while the rank array holds survivors only).
+__device__ __forceinline__ uint32_t rank_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
+                                                   const uint32_t* sym, uint32_t j) {
+    uint64_t key = 0;
+    for (int t = 0; t < r.m0; ++t) {
+        const uint32_t p = j + (uint32_t)t;
+        uint32_t c = 0;
+        if (p < r.len) c = sym[r.s[p]];
+        else if (p == r.len) c = r.dcode;
+        key = (key << r.sbits) | c;
+    }
+    const int kshift = r.ibits + 8;
+    uint32_t lo = 0, hi = r.n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((sorted0[mid] >> kshift) < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
 }
 
 template <int NT>
 __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
                                               uint8_t* __restrict__ out, uint64_t* bufA, uint64_t* bufB,
-                                              uint32_t* rank, FwdShared<NT>& sh, uint32_t* queue) {
+                                              uint32_t* rank, FwdShared<NT>& sh, const FwdArgs& a) {
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    uint32_t* queue = a.queue;
     const uint32_t n = len + 1;
     if (n == 1) {  // empty block: just the delimiter (reference tests/test_small.cpp:83)
         if (tid == 0) out[0] = (uint8_t)delim;
         return;
     }
+    PhaseClock pc;
+    pc.start(queue);
     // ---- 0. census and codes ------------------------------------------------
     if (tid < 256) sh.sym[tid] = 0;
     __syncthreads();
@@ -281,56 +491,68 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     const int sbits = bit_length(sigma);
     const int ibits = bit_length(n - 1);
     int m0 = (2 * ibits) / sbits;
-    const int m0cap = (64 - ibits) / sbits;
+    const int m0cap = min((64 - 8 - ibits) / sbits, kMaxM0);
     if (m0 > m0cap) m0 = m0cap;
     if (m0 < 1) m0 = 1;
     DigitPlan plan;
     plan.init(m0 * sbits);
-    zero_hist<NT>(sh.histA);
+    zero_hist<NT>(sh, 0);
     __syncthreads();
+    pc.lap(0);
 
-    // ---- 1. round 0: packed m0-symbol keys ---------------------------------------
-    {
-        Chunking ck;
-        ck.init(n, W);
-        const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, n);
-        const uint32_t dmask = (1u << plan.bits(0)) - 1u;
-        for (uint32_t base = lo; base < hi; base += kWave) {
-            const uint32_t i = base + lane;
-            if (i < hi) {
-                uint64_t key = 0;
-                for (int j = 0; j < m0; ++j) {
-                    const uint32_t p = i + j;
-                    uint32_t c = 0;
-                    if (p < n) c = sh.sym[p < len ? s[p] : delim];
-                    key = (key << sbits) | c;
-                }
-                bufA[i] = (key << ibits) | i;
-                atomicAdd(&sh.histA[w * kBins + ((uint32_t)key & dmask)], 1u);
-            }
-        }
-    }
+    // ---- 1. round 0: packed m0-symbol keys, generated straight into the first pass ----------
+    Round0 r0;
+    r0.s = s;
+    r0.g_lo = a.in;
+    r0.g_hi = a.in + a.total_len;
+    r0.len = len;
+    r0.n = n;
+    r0.dcode = sh.sym[delim];
+    r0.delim = delim;
+    r0.m0 = m0;
+    r0.sbits = sbits;
+    r0.ibits = ibits;
+    r0.kmask = (1ull << (m0 * sbits)) - 1ull;
+    const int kshift0 = ibits + 8;
+    round0_sweep<NT, 0>(r0, plan, nullptr, sh, 0, &queue[1]);
     __syncthreads();
-    uint64_t* cur = radix_sort<NT>(bufA, bufB, n, ibits, plan, sh.histA, sh.histB, sh.wsum, &queue[1]);
-    uint64_t* alt = (cur == bufA) ? bufB : bufA;
+    pc.lap(1);
+    if (plan.P > 1) zero_hist<NT>(sh, 1);
+    scan_hist<NT>(sh, 0);
+    round0_sweep<NT, 1>(r0, plan, bufA, sh, 0, &queue[1]);
+    __syncthreads();
+    uint64_t* const sorted0 = radix_sort<NT>(bufA, bufB, n, kshift0, plan, 1, sh, 1, &queue[1]);
+    uint64_t* const spare = (sorted0 == bufA) ? bufB : bufA;
+    pc.lap(2);
     // element layout for rounds >= 1: g | r2 | i, where r2 = rank[i+h] + 1, or 0 when the
     // suffix ends exactly at i+h (possible only if the delimiter also occurs inside the
     // block): "past the end" orders before every real rank, as in src/bwt.cpp:77-79
     const int rbits = bit_length(n);
     const int gshift = ibits + rbits;
+    BlockIO io;
+    io.s = s;
+    io.out = out;
+    io.n = n;
+    io.delim = delim;
     uint32_t m, G;
-    rerank<NT, true>(cur, alt, rank, n, ibits, gshift, sh, m, G);
+    bool full;
+    rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, false, sh, m, G, full);
+    pc.lap(3);
 
     // ---- 2. doubling rounds over the survivors -----------------------------------
+    // Buffers: while `full` is false the sorted round-0 array must stay intact (ranks are
+    // looked up in it), so the few survivors ping-pong inside the two halves of `spare`.
+    uint64_t* cur = full ? sorted0 : spare + a.ncap / 2;  // scratch side of the ping-pong
+    uint64_t* alt = spare;                                 // holds the survivor list
     uint32_t h = (uint32_t)m0;
     for (int round = 1; m > 0; ++round) {
-        if (round > 48) {  // cannot happen: h >= n is reached after at most 21 doublings
+        if (round > 64) {  // cannot happen: h >= n is reached after at most 21 doublings
             if (tid == 0) atomicOr(&queue[1], kErrNotConverged);
             break;
         }
         const int gbits = max(1, bit_length(G - 1));
         plan.init(rbits + gbits);
-        zero_hist<NT>(sh.histA);
+        zero_hist<NT>(sh, 0);
         __syncthreads();
         {
             Chunking ck;
@@ -338,23 +560,40 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, m);
             const uint32_t dmask = (1u << plan.bits(0)) - 1u;
             const uint64_t imask = (1ull << ibits) - 1ull;
+            uint32_t* myhist = sh.hist[0] + w * kBins;
             for (uint32_t base = lo; base < hi; base += kWave) {
                 const uint32_t k = base + lane;
                 if (k < hi) {
                     uint64_t e = alt[k];
-                    const uint32_t idx = (uint32_t)(e & imask);
-                    const uint32_t r2 = (idx + h < n) ? rank[idx + h] + 1u : 0u;
+                    const uint32_t j = (uint32_t)(e & imask) + h;
+                    uint32_t r2 = 0u;
+                    if (j < n) r2 = (full ? rank[j] : rank_by_search(sorted0, r0, sh.sym, j)) + 1u;
                     e |= (uint64_t)r2 << ibits;
                     alt[k] = e;
-                    atomicAdd(&sh.histA[w * kBins + ((uint32_t)(e >> ibits) & dmask)], 1u);
+                    atomicAdd(&myhist[(uint32_t)(e >> ibits) & dmask], 1u);
                 }
             }
         }
         __syncthreads();
-        uint64_t* sorted = radix_sort<NT>(alt, cur, m, ibits, plan, sh.histA, sh.histB, sh.wsum, &queue[1]);
+        pc.lap(4);
+        uint64_t* sorted = radix_sort<NT>(alt, cur, m, ibits, plan, 0, sh, 0, &queue[1]);
+        pc.lap(5);
         uint64_t* other = (sorted == alt) ? cur : alt;
         uint32_t m2, G2;
-        rerank<NT, false>(sorted, other, rank, m, ibits, gshift, sh, m2, G2);
+        bool unused;
+        rerank<NT, false>(sorted, other, rank, io, m, ibits, ibits, gshift, true, sh, m2, G2, unused);
+        pc.lap(6);
+        pc.count(9, 1);
+        if (!full) {
+            if (m2 == 0) break;
+            // survivors remain after the searched round: build the complete rank array from the
+            // round-0 order and redo this round with it (rare: long repeats in otherwise easy data)
+            rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, true, sh, m, G, full);
+            cur = sorted0;
+            alt = spare;
+            pc.lap(7);
+            continue;
+        }
         cur = sorted;
         alt = other;
         m = m2;
@@ -362,12 +601,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         h = (h >= 0x40000000u) ? 0x80000000u : h * 2u;
     }
     __syncthreads();
-    // ---- 3. gather --------------------------------------------------------------
-    for (uint32_t i = tid; i < n; i += NT) {
-        const uint32_t r = rank[i];
-        if (r < n) out[r] = (i == 0) ? (uint8_t)delim : s[i - 1];
-        else atomicOr(&queue[1], kErrBounds);
-    }
+    pc.count(8, 1);
 }
 
 template <int NT>
@@ -386,7 +620,7 @@ __global__ __launch_bounds__(NT) void bwt_forward_kernel(FwdArgs a) {
         const uint64_t rem = a.total_len - off;
         const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;
         forward_block<NT>(a.in + off, len, a.delim, a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u), bufA, bufB,
-                          rank, sh, a.queue);
+                          rank, sh, a);
         __syncthreads();
     }
 }

@@ -107,17 +107,17 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
             if (sh.drow[i] != kNoRow) drow = sh.drow[i];
         if (tid == 0) a.drow[b] = drow;
         // pass 2: LF table
-        volatile uint32_t* myoff = sh.hist + w * 256;
+        uint32_t* myoff = sh.hist + w * 256;
         for (uint32_t base = lo; base < hi; base += kWave) {
             const uint32_t k = base + lane;
             const bool valid = k < hi;
             const uint32_t c = valid ? L[k] : 0u;
-            const uint64_t peers = match_digit(c, 8, valid);
+            const uint64_t peers = match_digit<8>(c, valid);
             const uint32_t rk = __popcll(peers & lt);
-            const uint32_t cnt = __popcll(peers);
-            uint32_t b0 = 0;
-            if (valid) b0 = myoff[c];
-            if (valid && rk == 0) myoff[c] = b0 + cnt;
+            const uint32_t b0 = myoff[c];
+            compiler_fence();  // every lane has read its offset before the leaders advance it
+            if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
+            compiler_fence();
             if (valid) T[k] = (b0 + rk) | (c << 24);
         }
         __syncthreads();
