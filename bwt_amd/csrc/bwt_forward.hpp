@@ -314,24 +314,49 @@ struct RunFlags {
     bool valid, head, tail, ghead;
 };
 
-// Flags of sorted position k: head/tail of its equal-key run, head of its old group.
-template <bool ROUND0>
-__device__ __forceinline__ RunFlags run_flags(const uint64_t* __restrict__ cur, uint32_t k, uint32_t hi,
-                                              uint32_t m, int kshift, int gshift) {
-    RunFlags f;
-    f.valid = k < hi;
-    uint64_t e = 0, ep = 0, en = 0;
-    if (f.valid) {
-        e = cur[k];
-        if (k > 0) ep = cur[k - 1];
-        if (k + 1 < m) en = cur[k + 1];
+// Walks sorted positions [lo, hi) of cur[0..m) one 64-element vector at a time and hands the
+// body the flags of every position: head/tail of its equal-key run, head of its old group.
+// One coalesced load per vector, four vectors in flight; the neighbours' keys come from lane
+// shuffles (lane 0 / 63 take them from the previous / next vector).
+template <bool ROUND0, typename Body>
+__device__ __forceinline__ void for_each_run_vector(const uint64_t* __restrict__ cur, uint32_t lo, uint32_t hi,
+                                                    uint32_t m, int kshift, int gshift, Body body) {
+    constexpr int D = 4;
+    const int lane = lane_id();
+    if (lo >= hi) return;  // wave-uniform
+    uint64_t e[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        e[j] = 0;
+        if (lo + j * kWave + lane < m) e[j] = cur[lo + j * kWave + lane];
     }
-    const uint64_t key = e >> kshift;
-    f.head = f.valid && (k == 0 || (ep >> kshift) != key);
-    f.tail = f.valid && (k + 1 == m || (en >> kshift) != key);
-    f.ghead = f.valid && (k == 0 || (!ROUND0 && (ep >> gshift) != (e >> gshift)));
-    f.e = e;
-    return f;
+    uint64_t prev_last = lo > 0 ? cur[lo - 1] : 0ull;  // same address in every lane
+    for (uint32_t base = lo; base < hi; base += D * kWave) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t vb = base + j * kWave;
+            if (vb < hi) {  // wave-uniform
+                const uint32_t k = vb + lane;
+                const uint64_t ec = e[j];
+                const uint64_t nxt0 = __shfl(e[(j + 1) % D], 0);
+                uint64_t ep = __shfl_up(ec, 1);
+                uint64_t en = __shfl_down(ec, 1);
+                if (lane == 0) ep = prev_last;
+                if (lane == kWave - 1) en = nxt0;
+                prev_last = __shfl(ec, kWave - 1);
+                e[j] = 0;
+                if (k + D * kWave < m) e[j] = cur[k + D * kWave];
+                RunFlags f;
+                f.valid = k < hi;
+                f.e = ec;
+                const uint64_t key = ec >> kshift;
+                f.head = f.valid && (k == 0 || (ep >> kshift) != key);
+                f.tail = f.valid && (k + 1 == m || (en >> kshift) != key);
+                f.ghead = f.valid && (k == 0 || (!ROUND0 && (ep >> gshift) != (ec >> gshift)));
+                body(vb, f);
+            }
+        }
+    }
 }
 
 // What rerank needs to know about the block besides the sorted elements.
@@ -373,14 +398,13 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
     // phase A: per wave chunk, count survivors / surviving groups, find the last heads
     {
         uint32_t cA = 0, cG = 0, lH = 0, lG = 0;
-        for (uint32_t base = lo; base < hi; base += kWave) {
-            const RunFlags f = run_flags<ROUND0>(cur, base + lane, hi, m, kshift, gshift);
+        for_each_run_vector<ROUND0>(cur, lo, hi, m, kshift, gshift, [&](uint32_t base, const RunFlags& f) {
             const uint64_t H = __ballot(f.head), G = __ballot(f.ghead);
             cA += __popcll(__ballot(f.valid && !(f.head && f.tail)));
             cG += __popcll(__ballot(f.head && !f.tail));
             if (H) lH = base + 63u - (uint32_t)__clzll(H);
             if (G) lG = base + 63u - (uint32_t)__clzll(G);
-        }
+        });
         if (lane == 0) {
             sh.cntA[w] = cA;
             sh.cntG[w] = cG;
@@ -405,8 +429,7 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
     }
     const bool full = !ROUND0 || force_full || totA > m / 16u;
     // phase C: ranks, output bytes of finished suffixes, compaction of the rest
-    for (uint32_t base = lo; base < hi; base += kWave) {
-        const RunFlags f = run_flags<ROUND0>(cur, base + lane, hi, m, kshift, gshift);
+    for_each_run_vector<ROUND0>(cur, lo, hi, m, kshift, gshift, [&](uint32_t base, const RunFlags& f) {
         const uint64_t H = __ballot(f.head), G = __ballot(f.ghead);
         const uint64_t hm = H & le, gm = G & le;
         const uint32_t khead = hm ? base + 63u - (uint32_t)__clzll(hm) : carryH;
@@ -435,7 +458,7 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
         }
         baseA += __popcll(A);
         baseG += __popcll(NS);
-    }
+    });
     m_next = totA;
     g_next = totG;
     full_out = full;

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
 
 // One chain per block, one lane per chain.  Every step is a single dependent load; the
 // loop is bounded by the block length, and a well-formed block ends it exactly there by
-// walking back into the delimiter row.
+// walking back into the delimiter row.  Output bytes are produced back to front; they are
+// packed in registers and leave as aligned 16-byte stores (a lane-private store per byte
+// would be one scattered write per step).
 __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
     const uint32_t b = blockIdx.x * kWave + threadIdx.x;
     if (b >= a.nblocks) return;
@@ -138,17 +140,53 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
         return;
     }
     const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
-    uint8_t* __restrict__ o = a.out + (uint64_t)b * a.block_size;
+    uint8_t* const o = a.out + (uint64_t)b * a.block_size;
+    uint8_t* addr = o + len;  // lowest address written so far (exclusive end of what is left)
+    uint8_t* const floor_addr = o;
+    uint32_t acc = 0, cnt = 0;            // bytes of the dword in progress: acc's low byte is *addr
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, dcnt = 0;  // completed dwords, q0 lowest, at daddr + 4 j
+    uint8_t* daddr = addr;
     row = T[row] & kRowMask;
-    uint32_t p = len;
     for (uint32_t step = 0; step < n; ++step) {
         const uint32_t wd = T[row];
         const uint32_t ch = wd >> 24;
-        if (ch == a.delim || p == 0) break;
-        o[--p] = (uint8_t)ch;
+        if (ch == a.delim || addr == floor_addr) break;
         row = wd & kRowMask;
+        acc = (acc << 8) | ch;
+        ++cnt;
+        --addr;
+        if ((reinterpret_cast<uintptr_t>(addr) & 3u) == 0) {
+            if (cnt == 4) {
+                q3 = q2; q2 = q1; q1 = q0; q0 = acc;
+                daddr = addr;
+                ++dcnt;
+                if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
+                    if (dcnt == 4) {
+                        *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
+                    } else {
+                        uint32_t* d = reinterpret_cast<uint32_t*>(addr);
+                        d[0] = q0;
+                        if (dcnt > 1) d[1] = q1;
+                        if (dcnt > 2) d[2] = q2;
+                    }
+                    dcnt = 0;
+                }
+            } else {  // unaligned end of the block's slot: first dword is partial
+                for (uint32_t j = 0; j < cnt; ++j) addr[j] = (uint8_t)(acc >> (8 * j));
+            }
+            acc = 0;
+            cnt = 0;
+        }
     }
-    a.lens[b] = len - p;
+    for (uint32_t j = 0; j < cnt; ++j) addr[j] = (uint8_t)(acc >> (8 * j));
+    if (dcnt) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(daddr);
+        d[0] = q0;
+        if (dcnt > 1) d[1] = q1;
+        if (dcnt > 2) d[2] = q2;
+        if (dcnt > 3) d[3] = q3;
+    }
+    a.lens[b] = (uint32_t)((o + len) - addr);
 }
 
 }  // namespace bwtgpu
