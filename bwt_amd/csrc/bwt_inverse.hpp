@@ -8,20 +8,36 @@
 //   LF walk (:48-59)  row = delimiter_row; loop { row = C[L[row]] + occ[row]; ch = L[row];
 //                     stop at the first ch == delimiter; else emit ch }, result reversed (:61-62)
 //
-// Kernel 1 (one workgroup per block) builds the LF table T[i] = (C[L[i]] + occ[i]) | L[i] << 24:
-// an LDS byte histogram per wave chunk, an exclusive scan in (symbol, wave) order, then a
-// stable per-symbol ranking of every position (wave-ballot match, the same primitive as the
-// forward radix passes).  Packing the symbol next to the successor row makes the walk ONE
-// dependent 4-byte load per output byte.
-// Kernel 2 walks one independent chain per block, one lane per chain, emitting bytes back
-// to front so no reversal pass is needed.
+// Kernel 1, bwt_inverse_build_kernel (one workgroup per block): the LF table
+// T[i] = (C[L[i]] + occ[i]) | splitter flag << 23 | L[i] << 24 -- an LDS byte histogram per wave
+// chunk, an exclusive scan in (symbol, wave) order, then a stable per-symbol ranking of every
+// position (wave-ballot match, the same primitive as the forward radix passes).  Packing the
+// symbol next to the successor row makes a walk step ONE dependent 4-byte load.
+//
+// The walk itself is a pointer chase of n dependent loads; one chain per block leaves the
+// memory system idle, so a well-formed block (exactly one delimiter) is cut into segments:
+// every kSplitStride-th row and the delimiter row are "splitters"; one lane per splitter
+// walks until it reaches the next splitter (whose own byte it still emits), writing its bytes
+// into 256-byte chunks drawn
+// from a per-block pool (bwt_inverse_walk_segments_kernel).  A stitch pass orders the
+// segments by following next-splitter links from the delimiter row
+// (bwt_inverse_stitch_kernel) and a copy pass reverses every chunk into its final place
+// (bwt_inverse_place_kernel).  The result is the chain the reference walks, byte for byte.
+// Blocks with several delimiters (only possible for hand-made input) keep the reference's
+// exact semantics -- start at the last delimiter row, stop at the first delimiter reached --
+// through the single-chain kernel (bwt_inverse_walk_kernel), as do blocks too short to split.
 #pragma once
 #include "bwt_device.hpp"
 
 namespace bwtgpu {
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
-constexpr uint32_t kRowMask = 0x00FFFFFFu;
+constexpr uint32_t kRowMask = 0x007FFFFFu;   // successor row (n <= 2^21 < 2^23)
+constexpr uint32_t kSplitFlag = 0x00800000u; // this row starts a segment
+constexpr uint32_t kSplitStride = 1024;      // rows between regular splitters
+constexpr uint32_t kChunk = 256;             // bytes per pool chunk
+constexpr uint32_t kNoPos = 0xFFFFFFFFu;
+constexpr uint32_t kModeMulti = 0, kModeSingle = 1, kModeNone = 2;
 
 struct InvArgs {
     const uint8_t* in;    // block b reads in + b*(block_size+1)
@@ -31,8 +47,17 @@ struct InvArgs {
     uint32_t nblocks;
     uint32_t delim;
     uint32_t tstride;     // LF-table words per block (>= block_size+1)
+    uint32_t seg_cap;     // segment slots per block (regular splitters + 1)
+    uint32_t chunk_cap;   // pool chunks per block
     uint32_t* T;          // nblocks * tstride words
     uint32_t* drow;       // per block: delimiter row or kNoRow
+    uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
+    uint32_t* pool_used;  // per block: chunks handed out
+    uint32_t* seg_len;    // nblocks * seg_cap: bytes a segment produced
+    uint32_t* seg_next;   // nblocks * seg_cap: id of the splitter the segment ran into
+    uint32_t* seg_pos;    // nblocks * seg_cap: bytes between the segment's first byte and the text end
+    uint32_t* chunk_meta; // nblocks * chunk_cap: owner segment << 16 | ordinal within the segment
+    uint8_t* pool;        // nblocks * chunk_cap * kChunk bytes
     uint32_t* lens;       // per block: text length or BWTGPU_LEN_NO_DELIMITER
     uint32_t* queue;      // [0] next block index to hand out
 };
@@ -43,6 +68,7 @@ struct InvShared {
     uint32_t hist[W * 256];
     uint32_t wsum[W];
     uint32_t drow[W];
+    uint32_t ndelim;
     uint32_t blk;
 };
 
@@ -50,6 +76,11 @@ __device__ __forceinline__ uint32_t inv_block_len(const InvArgs& a, uint32_t b) 
     const uint64_t off = (uint64_t)b * ((uint64_t)a.block_size + 1u);
     const uint64_t rem = a.total_len - off;
     return rem < (uint64_t)a.block_size + 1u ? (uint32_t)rem : a.block_size + 1u;
+}
+
+// Regular splitters of a block of n rows: rows 0, stride, 2 stride, ...
+__device__ __host__ __forceinline__ uint32_t regular_splitters(uint32_t n) {
+    return (n + kSplitStride - 1u) / kSplitStride;
 }
 
 template <int NT>
@@ -91,6 +122,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
             uint32_t tot = 0;
             if (tid < 256)
                 for (int i = 0; i < W; ++i) tot += sh.hist[i * 256 + tid];
+            if (tid == (int)a.delim) sh.ndelim = tot;
             uint32_t total;
             uint32_t run = block_exclusive_scan<NT>(tot, sh.wsum, total);
             if (tid < 256)
@@ -105,7 +137,15 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
 #pragma unroll
         for (int i = 0; i < W; ++i)
             if (sh.drow[i] != kNoRow) drow = sh.drow[i];
-        if (tid == 0) a.drow[b] = drow;
+        // split the walk only when it is the plain single-delimiter case and long enough to pay
+        const uint32_t mode = drow == kNoRow ? kModeNone
+                              : (sh.ndelim == 1u && n >= 4u * kSplitStride) ? kModeMulti : kModeSingle;
+        if (tid == 0) {
+            a.drow[b] = drow;
+            a.mode[b] = mode;
+            a.pool_used[b] = 0;
+        }
+        const bool split = mode == kModeMulti;
         // pass 2: LF table
         uint32_t* myoff = sh.hist + w * 256;
         for (uint32_t base = lo; base < hi; base += kWave) {
@@ -118,12 +158,14 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
             compiler_fence();  // every lane has read its offset before the leaders advance it
             if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
             compiler_fence();
-            if (valid) T[k] = (b0 + rk) | (c << 24);
+            const uint32_t flag = (split && ((k & (kSplitStride - 1u)) == 0u || k == drow)) ? kSplitFlag : 0u;
+            if (valid) T[k] = (b0 + rk) | flag | (c << 24);
         }
         __syncthreads();
     }
 }
 
+// ---- single chain (short blocks, blocks with several delimiters) -------------------------------
 // One chain per block, one lane per chain.  Every step is a single dependent load; the
 // loop is bounded by the block length, and a well-formed block ends it exactly there by
 // walking back into the delimiter row.  Output bytes are produced back to front; they are
@@ -132,10 +174,12 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
 __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
     const uint32_t b = blockIdx.x * kWave + threadIdx.x;
     if (b >= a.nblocks) return;
+    const uint32_t mode = a.mode[b];
+    if (mode == kModeMulti) return;
     const uint32_t n = inv_block_len(a, b);
     const uint32_t len = n - 1;
     uint32_t row = a.drow[b];
-    if (row == kNoRow) {
+    if (mode == kModeNone || row == kNoRow) {
         a.lens[b] = 0xFFFFFFFFu;
         return;
     }
@@ -187,6 +231,121 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
         if (dcnt > 3) d[3] = q3;
     }
     a.lens[b] = (uint32_t)((o + len) - addr);
+}
+
+// ---- segmented walk -------------------------------------------------------------------------
+// Lane (b, j): segment j of block b.  j < regular_splitters(n) starts at row j * stride,
+// j == regular_splitters(n) starts at the delimiter row.  (A regular splitter that IS the
+// delimiter row is left to the latter.)
+__global__ __launch_bounds__(kWave) void bwt_inverse_walk_segments_kernel(InvArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * kWave + threadIdx.x;
+    const uint32_t b = (uint32_t)(gid / a.seg_cap);
+    const uint32_t j = (uint32_t)(gid % a.seg_cap);
+    if (b >= a.nblocks || a.mode[b] != kModeMulti) return;
+    const uint32_t n = inv_block_len(a, b);
+    const uint32_t nreg = regular_splitters(n);
+    if (j > nreg) return;
+    const uint32_t drow = a.drow[b];
+    const uint64_t sb = (uint64_t)b * a.seg_cap;
+    a.seg_pos[sb + j] = kNoPos;
+    a.seg_len[sb + j] = 0;
+    a.seg_next[sb + j] = j;
+    const uint32_t start = j < nreg ? j * kSplitStride : drow;
+    if (j < nreg && start == drow) return;
+    const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    uint8_t* const pool = a.pool + (uint64_t)b * a.chunk_cap * kChunk;
+    uint32_t* const meta = a.chunk_meta + (uint64_t)b * a.chunk_cap;
+    uint32_t row = T[start] & kRowMask;
+    uint32_t t = 0;  // bytes produced
+    uint32_t acc = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    uint8_t* chunk = nullptr;
+    uint32_t stop = start;
+    for (uint32_t step = 0; step < n; ++step) {
+        const uint32_t wd = T[row];
+        const bool at_splitter = (wd & kSplitFlag) != 0u;
+        if (at_splitter && row == drow) {  // back at the delimiter row: the text ends here
+            stop = row;
+            break;
+        }
+        if ((t & (kChunk - 1u)) == 0u) {  // need a fresh chunk
+            const uint32_t c = atomicAdd(&a.pool_used[b], 1u);
+            if (c >= a.chunk_cap) break;  // cannot happen: the pool holds n/kChunk + segments chunks
+            meta[c] = (j << 16) | (t / kChunk);
+            chunk = pool + (uint64_t)c * kChunk;
+        }
+        acc |= (wd >> 24) << (8u * (t & 3u));
+        ++t;
+        if ((t & 3u) == 0u) {
+            q0 = q1; q1 = q2; q2 = q3; q3 = acc;
+            acc = 0;
+            if ((t & 15u) == 0u)
+                *reinterpret_cast<uint4*>(chunk + ((t - 16u) & (kChunk - 1u))) = make_uint4(q0, q1, q2, q3);
+        }
+        if (at_splitter) {  // this row's byte belongs to this segment; the next segment starts after it
+            stop = row;
+            break;
+        }
+        row = wd & kRowMask;
+    }
+    if (t & 15u) {  // flush the partial 16-byte group (the chunk has room; bytes past t are never read)
+        const uint32_t have = (t & 15u) >> 2;  // complete dwords in the group: q3 newest
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        if (have == 0) { d0 = acc; }
+        else if (have == 1) { d0 = q3; d1 = acc; }
+        else if (have == 2) { d0 = q2; d1 = q3; d2 = acc; }
+        else { d0 = q1; d1 = q2; d2 = q3; d3 = acc; }
+        *reinterpret_cast<uint4*>(chunk + ((t & ~15u) & (kChunk - 1u))) = make_uint4(d0, d1, d2, d3);
+    }
+    a.seg_len[sb + j] = t;
+    a.seg_next[sb + j] = stop == drow ? nreg : stop / kSplitStride;
+}
+
+// Orders the segments of every split block: start at the delimiter row's segment, follow the
+// next-splitter links until the chain returns to it.  seg_pos = bytes before the segment,
+// counted from the END of the text (the walk produces the text back to front).
+__global__ __launch_bounds__(kWave) void bwt_inverse_stitch_kernel(InvArgs a) {
+    const uint32_t b = blockIdx.x * kWave + threadIdx.x;
+    if (b >= a.nblocks || a.mode[b] != kModeMulti) return;
+    const uint32_t n = inv_block_len(a, b);
+    const uint32_t nreg = regular_splitters(n);
+    const uint64_t sb = (uint64_t)b * a.seg_cap;
+    uint32_t id = nreg, total = 0;
+    for (uint32_t it = 0; it <= nreg; ++it) {
+        a.seg_pos[sb + id] = total;
+        total += a.seg_len[sb + id];
+        const uint32_t nx = a.seg_next[sb + id];
+        if (nx >= nreg) break;  // back at the delimiter row: the text is complete
+        id = nx;
+    }
+    a.lens[b] = total < n ? total : n - 1;
+}
+
+// Moves every chunk of a chained segment to its place, reversed.  One workgroup per block.
+template <int NT>
+__global__ __launch_bounds__(NT) void bwt_inverse_place_kernel(InvArgs a) {
+    const uint32_t b = blockIdx.x;
+    if (a.mode[b] != kModeMulti) return;
+    const uint32_t n = inv_block_len(a, b);
+    const uint32_t used = min(a.pool_used[b], a.chunk_cap);
+    const uint64_t sb = (uint64_t)b * a.seg_cap;
+    const uint8_t* const pool = a.pool + (uint64_t)b * a.chunk_cap * kChunk;
+    const uint32_t* const meta = a.chunk_meta + (uint64_t)b * a.chunk_cap;
+    uint8_t* const text_end = a.out + (uint64_t)b * a.block_size + (n - 1);
+    const int lane = lane_id();
+    for (uint32_t c = wave_id(); c < used; c += NT / kWave) {
+        const uint32_t mt = meta[c];
+        const uint32_t seg = mt >> 16, ord = mt & 0xFFFFu;
+        const uint32_t pos = a.seg_pos[sb + seg];
+        if (pos == kNoPos) continue;  // a segment on a cycle the delimiter's chain never reaches
+        const uint32_t slen = a.seg_len[sb + seg];
+        const uint32_t off = ord * kChunk;
+        if (off >= slen) continue;
+        const uint32_t cnt = min(kChunk, slen - off);
+        const uint8_t* src = pool + (uint64_t)c * kChunk;
+        const uint64_t back = (uint64_t)pos + off;  // bytes between text_end and this chunk's first byte
+        if (back + cnt > (uint64_t)(n - 1)) continue;  // never: the chain is at most n-1 bytes long
+        for (uint32_t u = lane; u < cnt; u += kWave) text_end[-(int64_t)(back + u) - 1] = src[u];
+    }
 }
 
 }  // namespace bwtgpu
