@@ -9,7 +9,11 @@
 namespace bwtgpu {
 
 constexpr int kWave = 64;
-constexpr int kMaxDigitBits = 9;            // widest LSD radix digit
+// LSD radix digit: 6 bits = 64 bins = one bin per lane of a wave.  Narrow digits keep the runs a
+// staged tile writes per bin long (a 1024-element tile gives 16-element = 128-byte runs on
+// average); measured on MI355X, 8-byte stores in runs of 64 B or more go ~4x faster per element
+// than in runs of 32 B and ~14x faster than lane-scattered ones.
+constexpr int kMaxDigitBits = 6;
 constexpr int kBins = 1 << kMaxDigitBits;   // LDS histogram bins per wave
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
@@ -45,6 +49,17 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
 // one wave hand values to each other through LDS and the order of a read and a later write
 // matters).
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+
+// Inclusive prefix sum across the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t y = __shfl_up(v, o);
+        if (lane >= o) v += y;
+    }
+    return v;
+}
 
 // Exclusive prefix sum of one value per thread over the workgroup; `total` receives
 // the workgroup sum.  s_wsum needs NT/64 words.  Contains two barriers.

@@ -50,6 +50,8 @@ constexpr uint32_t kErrBounds = 2u;
 constexpr int kMaxM0 = 17;    // symbols per round-0 key (bounded by the 24-byte rolling window)
 constexpr int kRun = 8;       // consecutive positions one lane rolls through in round 0
 constexpr int kTile = kRun * kWave;  // positions per wave iteration in round 0
+constexpr int kTileVecs = 14;        // 64-element vectors a wave stages per tile in a radix pass (fits 3 workgroups' LDS per CU)
+constexpr int kTileElems = kTileVecs * kWave;
 
 // Per-phase time accounting (100 MHz constant clock), summed over workgroups into
 // queue[16..] as u64: 0 census, 1 round-0 digit count, 2 round-0 sort, 3 round-0 rerank,
@@ -76,8 +78,13 @@ struct PhaseClock {
 template <int NT>
 struct FwdShared {
     static constexpr int W = NT / kWave;
-    uint32_t hist[2][W * kBins];  // per-wave digit counts / scatter offsets, double buffered
-    uint32_t sym[256];            // byte value -> code
+    uint64_t tin[W][kTileElems];    // per-wave staging tile, elements in arrival order
+    uint16_t trk[W][kTileElems];    // per element: digit << 10 | rank among the tile's elements with that digit
+    uint16_t perm[W][kTileElems];   // tile position after grouping by digit -> arrival slot
+    uint32_t hist[2][W * kBins];    // per-wave digit counts / scatter offsets, double buffered
+    uint32_t tcnt[W][kBins];        // per-wave, per-tile digit counts, then tile-local run starts
+    uint32_t tdel[W][kBins];        // per-wave: global slot of a run's first element minus its tile index
+    uint32_t sym[256];              // byte value -> code
     uint32_t wsum[W];
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
     uint32_t blk;
@@ -119,63 +126,108 @@ __device__ __forceinline__ void scan_hist(FwdShared<NT>& sh, int sel) {
     __syncthreads();
 }
 
-// Places one element per lane: stable rank among the lanes of this wave vector that hold
-// the same digit (ballot match), next free slot of the digit from the wave's LDS offsets,
-// scatter to dst, and the NEXT pass's digit counted per destination wave chunk.
-template <int BITS>
-__device__ __forceinline__ void rank_and_scatter(uint64_t e, bool valid, uint32_t d, uint32_t* myoff,
-                                                 uint64_t* __restrict__ dst, uint32_t m, bool has_next,
-                                                 int nshift, uint32_t nmask, const Chunking& ck,
-                                                 uint32_t* nhist, uint32_t* err) {
-    const uint64_t peers = match_digit<BITS>(d, valid);
-    const uint32_t rk = __popcll(peers & lanemask_lt());
-    const uint32_t b0 = myoff[valid ? d : 0u];
-    compiler_fence();  // every lane has read its offset before the leaders advance it
-    if (valid && rk == 0) myoff[d] = b0 + (uint32_t)__popcll(peers);
+// One wave scatters the tile it has staged in LDS (tin[64 v + lane], v < nvec, in arrival
+// order; valid_of(v) tells whether this lane's element of vector v exists) by `digit`, stably:
+//   1. stable rank of every element among the tile's elements with the same digit: ballot match
+//      inside a vector, running per-digit counts (one LDS word per digit) across vectors;
+//   2. exclusive scan of the 64 digit counts across the wave's 64 lanes -> where each digit's run
+//      starts inside the tile; the wave's global per-digit cursors advance by the counts;
+//   3. perm[run start + rank] = arrival slot: the tile's order after grouping by digit;
+//   4. the tile leaves in that order: lane i's element goes to (global cursor of its digit) +
+//      (i - run start), so consecutive lanes write consecutive slots -- whole runs (128 B on
+//      average) instead of lane-scattered 8-byte stores.
+// The NEXT pass's digit is counted per destination wave chunk on the way out.
+// All loops are rolled and everything lives in LDS, so the register footprint stays small.
+template <int NT, typename ValidOf, typename DigitOf>
+__device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, DigitOf digit_of,
+                                               uint64_t* __restrict__ dst, uint32_t m, bool has_next, int nshift,
+                                               uint32_t nmask, const Chunking& ck, FwdShared<NT>& sh, int sel,
+                                               uint32_t* err) {
+    const int lane = lane_id(), w = wave_id();
+    uint32_t* myoff = sh.hist[sel] + w * kBins;
+    uint32_t* nhist = sh.hist[sel ^ 1];
+    uint32_t* tcnt = sh.tcnt[w];
+    uint32_t* tdel = sh.tdel[w];
+    const uint64_t* tin = sh.tin[w];
+    uint16_t* trk = sh.trk[w];
+    uint16_t* perm = sh.perm[w];
+    const uint64_t lt = lanemask_lt();
+    tcnt[lane] = 0;
     compiler_fence();
-    if (valid) {
-        const uint32_t pos = b0 + rk;
-        if (pos < m) {
-            dst[pos] = e;
-            if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + ((uint32_t)(e >> nshift) & nmask)], 1u);
-        } else {
-            atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
+    for (int v = 0; v < nvec; ++v) {
+        const bool ok = valid_of(v);
+        const uint32_t d = digit_of(tin[v * kWave + lane]);
+        const uint64_t peers = match_digit<kMaxDigitBits>(d, ok);
+        const uint32_t rk = __popcll(peers & lt);
+        const uint32_t b0 = tcnt[ok ? d : 0u];
+        compiler_fence();  // every lane has read the count before the leaders advance it
+        if (ok && rk == 0) tcnt[d] = b0 + (uint32_t)__popcll(peers);
+        compiler_fence();
+        trk[v * kWave + lane] = (uint16_t)((d << 10) | (b0 + rk));
+    }
+    const uint32_t c = tcnt[lane];
+    const uint32_t incl = wave_inclusive_scan(c);
+    const uint32_t excl = incl - c;
+    const uint32_t total = __shfl(incl, kWave - 1);
+    const uint32_t g0 = myoff[lane];
+    compiler_fence();
+    tcnt[lane] = excl;
+    tdel[lane] = g0 - excl;
+    myoff[lane] = g0 + c;
+    compiler_fence();
+    for (int v = 0; v < nvec; ++v) {
+        if (valid_of(v)) {
+            const uint32_t t = trk[v * kWave + lane];
+            perm[tcnt[t >> 10] + (t & 1023u)] = (uint16_t)(v * kWave + lane);
         }
     }
+    compiler_fence();
+    for (uint32_t i0 = 0; i0 < total; i0 += kWave) {
+        const uint32_t i = i0 + lane;
+        if (i < total) {
+            const uint64_t x = tin[perm[i]];
+            const uint32_t pos = tdel[digit_of(x)] + i;
+            if (pos < m) {
+                dst[pos] = x;
+                if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + ((uint32_t)(x >> nshift) & nmask)], 1u);
+            } else {
+                atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
+            }
+        }
+    }
+    compiler_fence();
 }
 
-// One stable LSD pass over src[0..m): each wave walks its contiguous chunk one 64-element
-// vector at a time, four vectors prefetched ahead.
-template <int NT, int BITS>
+// One stable LSD pass over src[0..m): each wave walks its contiguous chunk one staged tile
+// (kTileVecs vectors) at a time.
+template <int NT>
 __device__ __forceinline__ void radix_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
                                            uint32_t m, const Chunking& ck, int shift, int bits, bool has_next,
                                            int nshift, int nbits, FwdShared<NT>& sh, int sel, uint32_t* err) {
     const int lane = lane_id(), w = wave_id();
     const uint32_t lo = (uint32_t)w * ck.chunk;
     const uint32_t hi = min(lo + ck.chunk, m);
-    uint32_t* myoff = sh.hist[sel] + w * kBins;
-    uint32_t* nhist = sh.hist[sel ^ 1];
-    const uint32_t mask = (1u << bits) - 1u, nmask = (1u << nbits) - 1u;  // bits <= BITS
-    // four vectors in flight per wave: each register is refilled right after it is consumed
-    constexpr int D = 4;
-    uint64_t e[D];
+    const uint32_t mask = (1u << bits) - 1u, nmask = (1u << nbits) - 1u;
+    uint64_t* tin = sh.tin[w];
+    auto digit_of = [=](uint64_t x) { return (uint32_t)(x >> shift) & mask; };
+    for (uint32_t base = lo; base < hi; base += kTileElems) {
+        const uint32_t cnt = min((uint32_t)kTileElems, hi - base);
+        const int nvec = (int)((cnt + kWave - 1) / kWave);
+        // stage the tile: seven loads in flight per lane, then LDS in arrival order
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        e[j] = 0;
-        if (lo + j * kWave + lane < hi) e[j] = src[lo + j * kWave + lane];
-    }
-    for (uint32_t base = lo; base < hi; base += D * kWave) {
+        for (int h = 0; h < 2; ++h) {
+            uint64_t e[kTileVecs / 2];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const uint32_t k = base + j * kWave + lane;
-            if (base + j * kWave < hi) {  // wave-uniform
-                const uint64_t cur = e[j];
-                e[j] = 0;
-                if (k + D * kWave < hi) e[j] = src[k + D * kWave];
-                rank_and_scatter<BITS>(cur, k < hi, (uint32_t)(cur >> shift) & mask, myoff, dst, m, has_next, nshift,
-                                       nmask, ck, nhist, err);
+            for (int j = 0; j < kTileVecs / 2; ++j) {
+                const uint32_t i = (uint32_t)((h * (kTileVecs / 2) + j) * kWave + lane);
+                e[j] = i < cnt ? src[base + i] : 0ull;
             }
+#pragma unroll
+            for (int j = 0; j < kTileVecs / 2; ++j) tin[(h * (kTileVecs / 2) + j) * kWave + lane] = e[j];
         }
+        compiler_fence();
+        auto valid_of = [=](int v) { return (uint32_t)(v * kWave + lane) < cnt; };
+        scatter_staged<NT>(nvec, valid_of, digit_of, dst, m, has_next, nshift, nmask, ck, sh, sel, err);
     }
 }
 
@@ -195,11 +247,7 @@ __device__ __forceinline__ uint64_t* radix_sort(uint64_t* a, uint64_t* b, uint32
         const int shift = key_shift + plan.shift(p);
         const int nshift = key_shift + plan.shift(has_next ? p + 1 : p);
         const int nbits = plan.bits(has_next ? p + 1 : p);
-        const int bits = plan.bits(p);
-        // the digit is at most `bits` wide, so matching on more bits is exact (they are zero)
-        if (bits > 8) radix_pass<NT, 9>(a, b, m, ck, shift, bits, has_next, nshift, nbits, sh, sel, err);
-        else if (bits > 6) radix_pass<NT, 8>(a, b, m, ck, shift, bits, has_next, nshift, nbits, sh, sel, err);
-        else radix_pass<NT, 6>(a, b, m, ck, shift, bits, has_next, nshift, nbits, sh, sel, err);
+        radix_pass<NT>(a, b, m, ck, shift, plan.bits(p), has_next, nshift, nbits, sh, sel, err);
         __syncthreads();
         uint64_t* t = a; a = b; b = t;
         sel ^= 1;
@@ -248,7 +296,6 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
     Chunking ck;
     ck.init(r.n, W);
     uint32_t* myoff = sh.hist[sel] + w * kBins;
-    uint32_t* nhist = sh.hist[sel ^ 1];
     const uint32_t dmask = (1u << plan.bits(0)) - 1u;
     const bool has_next = plan.P > 1;
     const int kshift = r.ibits + 8;
@@ -281,6 +328,8 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
             prevw[1] = __builtin_amdgcn_alignbyte(p2, p1, pmis);
         }
         uint64_t key = 0;
+        uint64_t el[kRun];
+        uint32_t valid_bits = 0;
 #pragma unroll
         for (int t = 0; t < 16 + kRun; ++t) {
             if (t >= lead) {  // wave-uniform
@@ -291,20 +340,28 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
                 key = ((key << r.sbits) | c) & r.kmask;
             }
             if (t >= 16) {
-                const uint32_t pe = q0 + (uint32_t)(t - 16);
+                const int j = t - 16;
+                const uint32_t pe = q0 + (uint32_t)j;
                 const bool valid = pe < hi;
-                const uint32_t d = (uint32_t)key & dmask;
                 if (MODE == 0) {
-                    if (valid) atomicAdd(&myoff[d], 1u);
+                    if (valid) atomicAdd(&myoff[(uint32_t)key & dmask], 1u);
                 } else {
-                    const int j = t - 16;
                     uint32_t prev = (prevw[j >> 2] >> (8 * (j & 3))) & 255u;
                     if (pe == 0) prev = r.delim;  // the row of suffix 0 carries the delimiter (src/bwt.cpp:115-116)
-                    const uint64_t e = (key << kshift) | ((uint64_t)prev << r.ibits) | pe;
-                    rank_and_scatter<kMaxDigitBits>(e, valid, d, myoff, dst, r.n, has_next, nshift, nmask, ck, nhist,
-                                                    err);
+                    el[j] = (key << kshift) | ((uint64_t)prev << r.ibits) | pe;
+                    if (valid) valid_bits |= 1u << j;
                 }
             }
+        }
+        if (MODE == 1) {
+            // pass 0 needs no particular order among equal digits, so the lane-run layout is fine
+            uint64_t* tin = sh.tin[w];
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) tin[j * kWave + lane] = el[j];
+            compiler_fence();
+            auto digit_of = [=](uint64_t x) { return (uint32_t)(x >> kshift) & dmask; };
+            auto valid_of = [=](int v) { return (valid_bits >> v) & 1u; };
+            scatter_staged<NT>(kRun, valid_of, digit_of, dst, r.n, has_next, nshift, nmask, ck, sh, sel, err);
         }
     }
 }

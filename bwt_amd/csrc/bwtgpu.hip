@@ -18,7 +18,7 @@ namespace {
 
 using namespace bwtgpu;
 
-constexpr int kFwdThreads = 512;   // forward: threads per workgroup
+constexpr int kFwdThreads = 256;   // forward: threads per workgroup (4 waves, each with an 8 KiB LDS staging tile)
 constexpr int kInvThreads = 256;   // inverse table build: threads per workgroup
 constexpr size_t kHeaderBytes = 256;  // workspace header: work queue + status words
 

@@ -43,6 +43,13 @@ __global__ __launch_bounds__(512) void k(uint8_t* base, size_t region, int iters
             const uint32_t d = hash32((it * 8 + w) * 8 + r + blockIdx.x * 977) % bins;
             const uint32_t pos = d * seg + ((it * 8 + w) * 8 + (lane & 7)) % seg;
             reinterpret_cast<uint64_t*>(my)[pos] = ((uint64_t)h << 32) | g;
+        } else if (MODE >= 10) {
+            // runs of RL = MODE-10 lanes: run r -> random bin, consecutive slots inside the run
+            const uint32_t RL = MODE - 10;
+            const uint32_t r = lane / RL;
+            const uint32_t d = hash32((it * 8 + w) * 64 + r + blockIdx.x * 977) % bins;
+            const uint32_t pos = d * seg + (hash32(it * 8 + w) * RL + (lane % RL)) % seg;
+            reinterpret_cast<uint64_t*>(my)[pos] = ((uint64_t)h << 32) | g;
         }
     }
     if (MODE == 4 && acc == 0x12345678) sink[0] = acc;
@@ -71,20 +78,19 @@ int main() {
     CK(hipMalloc(&d, region * maxgrid)); CK(hipMalloc(&sink, 64));
     CK(hipMemset(d, 0, region * maxgrid));
     const int iters = 512;  // 512*512 = 262144 elements per workgroup
-    for (int grid : {256, 512, 768, 1024}) {
+    for (int grid : {512, 768}) {
         run<1>("8B store coalesced", d, region, grid, iters, 1, sink, 8);
-        for (int bins : {16, 64, 512}) run<0>("8B store, random bin per lane", d, region, grid, iters, bins, sink, 8);
-        run<5>("8B store, 8 runs of 8 lanes (LDS-staged)", d, region, grid, iters, 512, sink, 8);
-        run<2>("4B store random in 4 MB", d, region, grid, iters, 1, sink, 4);
-        run<3>("1B store random in 4 MB", d, region, grid, iters, 1, sink, 1);
+        run<11>("8B store runs of 1 lane", d, region, grid, iters, 512, sink, 8);
+        run<12>("8B store runs of 2 lanes (16 B)", d, region, grid, iters, 512, sink, 8);
+        run<14>("8B store runs of 4 lanes (32 B)", d, region, grid, iters, 512, sink, 8);
+        run<18>("8B store runs of 8 lanes (64 B)", d, region, grid, iters, 512, sink, 8);
+        run<26>("8B store runs of 16 lanes (128 B)", d, region, grid, iters, 512, sink, 8);
+        run<42>("8B store runs of 32 lanes (256 B)", d, region, grid, iters, 512, sink, 8);
         run<4>("4B load random in 4 MB", d, region, grid, iters, 1, sink, 4);
     }
-    // smaller window: rank array of a 256 KiB block is 1 MB, output block 256 KB
-    const size_t small = 1u << 20;
-    for (int grid : {512, 1024}) {
-        run<2>("4B store random in 1 MB", d, small, grid, iters, 1, sink, 4);
-        run<3>("1B store random in 1 MB", d, small, grid, iters, 1, sink, 1);
-        run<4>("4B load random in 1 MB", d, small, grid, iters, 1, sink, 4);
+    for (int grid : {256, 512}) {
+        run<4>("4B load random in 512 KB (L2/MALL resident)", d, 512u << 10, grid, iters, 1, sink, 4);
+        run<4>("4B load random in 256 KB", d, 256u << 10, grid, iters, 1, sink, 4);
     }
     return 0;
 }
