@@ -83,8 +83,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--bytes-per-gpu", type=int, default=0, help="override the shard size (bytes)")
+    ap.add_argument("--block-size", type=int, default=0, help="override the block size (exploration only)")
+    ap.add_argument("--kind", default="", help="override the generator kind (exploration only)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the one-step runs of the other benchmark configurations")
     ap.add_argument("--cpu-baseline-worker", nargs=5, metavar=("KIND", "BS", "SAMPLE", "SEED", "CORES"))
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -113,44 +117,18 @@ def main() -> None:
     kind, bs, nbytes, cfg, desc = WORKLOADS[args.workload]
     if args.bytes_per_gpu:
         nbytes = args.bytes_per_gpu
-    seed = synth.base_seed(cfg)
+    if args.block_size:
+        bs = args.block_size
+    if args.kind:
+        kind = args.kind
     L = api.lib()
     api.init(0)
     stream = torch.cuda.current_stream().cuda_stream
-    nblocks = L.bwtgpu_num_blocks(nbytes, bs)
-    fwd_bytes = nbytes + nblocks
+    text = open(os.path.join(ROOT, "data", "canterbury_corpus", "alice29.txt"), "rb").read()
+    d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
 
     def dptr(t):
         return ctypes.c_void_p(t.data_ptr())
-
-    # ---- shard `rank` of the global synthetic stream, generated in HBM -------------------------
-    text = open(os.path.join(ROOT, "data", "canterbury_corpus", "alice29.txt"), "rb").read()
-    d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
-    d_in = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    d_fwd = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
-    d_back = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    d_lens = torch.empty(nblocks, dtype=torch.int32, device=dev)
-    ws_f = L.bwtgpu_forward_workspace_bytes(local_rank, nbytes, bs)
-    ws_i = L.bwtgpu_inverse_workspace_bytes(local_rank, fwd_bytes, bs)
-    d_ws_f = torch.empty(ws_f, dtype=torch.uint8, device=dev)
-    d_ws_i = torch.empty(ws_i, dtype=torch.uint8, device=dev)
-    api.check(L.bwtgpu_synth_device(local_rank, synth.KINDS[kind], seed, rank * nbytes, dptr(d_in), nbytes,
-                                    dptr(d_text), d_text.numel(), stream))
-    # delimiter: lowest byte value absent from the WHOLE dataset = OR of the shards' presence masks
-    d_mask = torch.zeros(8, dtype=torch.int32, device=dev)
-    api.check(L.bwtgpu_presence_device(local_rank, dptr(d_in), nbytes, dptr(d_mask), stream))
-    flags = shard.mask_words_to_flags([v & 0xFFFFFFFF for v in d_mask.cpu().tolist()])
-    delim = shard.agree_on_delimiter(flags, device=dev)  # 256 flags, set-up only: not on the timed path
-    if delim < 0:
-        raise SystemExit("the workload uses all 256 byte values: the format has no delimiter for it")
-
-    def forward():
-        api.check(L.bwtgpu_forward_batch_device(local_rank, dptr(d_in), nbytes, bs, delim, dptr(d_fwd), dptr(d_ws_f),
-                                                d_ws_f.numel(), stream))
-
-    def inverse():
-        api.check(L.bwtgpu_inverse_batch_device(local_rank, dptr(d_fwd), fwd_bytes, bs, delim, dptr(d_back),
-                                                dptr(d_lens), dptr(d_ws_i), d_ws_i.numel(), stream))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -158,40 +136,79 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        forward()
-        inverse()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    sync_all()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        ev[s][0].record()
-        forward()
-        ev[s][1].record()
-        inverse()
-        ev[s][2].record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    def measure(kind, bs, nbytes, cfg, steps, warmup):
+        """One workload: generate the shard in HBM, time `steps` forward+inverse passes, verify."""
+        seed = synth.base_seed(cfg)
+        nblocks = L.bwtgpu_num_blocks(nbytes, bs)
+        fwd_bytes = nbytes + nblocks
+        # ---- shard `rank` of the global synthetic stream, generated in HBM ---------------------
+        d_in = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        d_fwd = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+        d_back = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        d_lens = torch.empty(nblocks, dtype=torch.int32, device=dev)
+        ws_f = L.bwtgpu_forward_workspace_bytes(local_rank, nbytes, bs)
+        ws_i = L.bwtgpu_inverse_workspace_bytes(local_rank, fwd_bytes, bs)
+        d_ws_f = torch.empty(ws_f, dtype=torch.uint8, device=dev)
+        d_ws_i = torch.empty(ws_i, dtype=torch.uint8, device=dev)
+        api.check(L.bwtgpu_synth_device(local_rank, synth.KINDS[kind], seed, rank * nbytes, dptr(d_in), nbytes,
+                                        dptr(d_text), d_text.numel(), stream))
+        # delimiter: lowest byte value absent from the WHOLE dataset = OR of the shards' presence masks
+        d_mask = torch.zeros(8, dtype=torch.int32, device=dev)
+        api.check(L.bwtgpu_presence_device(local_rank, dptr(d_in), nbytes, dptr(d_mask), stream))
+        flags = shard.mask_words_to_flags([v & 0xFFFFFFFF for v in d_mask.cpu().tolist()])
+        delim = shard.agree_on_delimiter(flags, device=dev)  # 256 flags, set-up only: not on the timed path
+        if delim < 0:
+            raise SystemExit("the workload uses all 256 byte values: the format has no delimiter for it")
 
-    # ---- checks outside the timed region ------------------------------------------------------
-    roundtrip_ok = bool(torch.equal(d_in, d_back))
-    lens_ok = bool((d_lens[:-1] == bs).all().item()) and int(d_lens[-1].item()) == nbytes - (nblocks - 1) * bs
-    status = d_ws_f[:8].cpu().numpy().view("uint32")  # [1] = forward kernel error flags
-    ph = d_ws_f[64:64 + 80].cpu().numpy().view("uint64").astype(float)
-    names = ["census", "keys0", "sort0", "rerank0", "keys", "sort", "rerank", "gather"]
-    tot = max(1.0, float(ph[:8].sum()))
-    phase_share = {k: round(float(v) / tot, 4) for k, v in zip(names, ph[:8])}
-    phase_share["later_rounds_per_block"] = round(float(ph[9]) / max(1.0, float(ph[8])), 3)
-    ok = torch.tensor([int(roundtrip_ok and lens_ok and int(status[1]) == 0)], device=dev)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    all_ok = bool(ok.item())
+        def forward():
+            api.check(L.bwtgpu_forward_batch_device(local_rank, dptr(d_in), nbytes, bs, delim, dptr(d_fwd),
+                                                    dptr(d_ws_f), d_ws_f.numel(), stream))
+
+        def inverse():
+            api.check(L.bwtgpu_inverse_batch_device(local_rank, dptr(d_fwd), fwd_bytes, bs, delim, dptr(d_back),
+                                                    dptr(d_lens), dptr(d_ws_i), d_ws_i.numel(), stream))
+
+        for _ in range(warmup):
+            forward()
+            inverse()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        sync_all()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            ev[s][0].record()
+            forward()
+            ev[s][1].record()
+            inverse()
+            ev[s][2].record()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+        inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+        # ---- checks outside the timed region ---------------------------------------------------
+        roundtrip_ok = bool(torch.equal(d_in, d_back))
+        lens_ok = (bool((d_lens[:-1] == bs).all().item())
+                   and int(d_lens[-1].item()) == nbytes - (nblocks - 1) * bs)
+        status = d_ws_f[:8].cpu().numpy().view("uint32")  # [1] = forward kernel error flags
+        ph = d_ws_f[64:64 + 80].cpu().numpy().view("uint64").astype(float)
+        names = ["census", "keys0_count", "sort0", "rerank0", "keys", "sort", "rerank", "rank_rebuild"]
+        tot = max(1.0, float(ph[:8].sum()))
+        phase_share = {k: round(float(v) / tot, 4) for k, v in zip(names, ph[:8])}
+        phase_share["later_rounds_per_block"] = round(float(ph[9]) / max(1.0, float(ph[8])), 3)
+        ok = torch.tensor([int(roundtrip_ok and lens_ok and int(status[1]) == 0)], device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return {"elapsed": elapsed, "fwd_ms": fwd_ms, "inv_ms": inv_ms, "ok": bool(ok.item()),
+                "status": int(status[1]), "phase_share": phase_share, "delim": delim, "nblocks": nblocks,
+                "fwd_bytes": fwd_bytes, "d_fwd": d_fwd, "seed": seed}
+
+    r = measure(kind, bs, nbytes, cfg, args.steps, args.warmup)
+    elapsed, fwd_ms, inv_ms, all_ok = r["elapsed"], r["fwd_ms"], r["inv_ms"], r["ok"]
+    nblocks, fwd_bytes, delim, d_fwd, seed = r["nblocks"], r["fwd_bytes"], r["delim"], r["d_fwd"], r["seed"]
+    phase_share, status1 = r["phase_share"], r["status"]
 
     if rank == 0:
         cpu = None
@@ -247,9 +264,29 @@ def main() -> None:
             "inverse_GBps": nbytes / (inv_ms * 1e-3) / 1e9,
             "roundtrip_pct_of_hbm_roofline": 100.0 * (4 * nbytes + 2 * nblocks) * world / step_s / (HBM_PEAK * world),
             "roundtrip_verified": all_ok,
-            "kernel_status": int(status[1]),
+            "kernel_status": status1,
             "forward_phase_share": phase_share,
         }
+    # ---- the other benchmark configurations, one timed step each (same code path) ---------------
+    others = []
+    if not args.no_other_workloads and not (args.block_size or args.kind or args.bytes_per_gpu):
+        del r, d_fwd
+        torch.cuda.empty_cache()
+        for name in sorted(WORKLOADS):
+            if name == args.workload:
+                continue
+            k2, bs2, nb2, cfg2, desc2 = WORKLOADS[name]
+            r2 = measure(k2, bs2, nb2, cfg2, 1, 1)
+            others.append({"workload": name, "block_size": bs2, "bytes_per_gpu": nb2,
+                           "value": nb2 * world / r2["elapsed"] / 1e9, "unit": "GB/s",
+                           "forward_ms": r2["fwd_ms"], "inverse_ms": r2["inv_ms"],
+                           "roundtrip_verified": r2["ok"],
+                           "later_rounds_per_block": r2["phase_share"]["later_rounds_per_block"]})
+            all_ok = all_ok and r2["ok"]
+            del r2
+            torch.cuda.empty_cache()
+    if rank == 0:
+        line["other_workloads"] = others
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
