@@ -50,8 +50,15 @@ constexpr uint32_t kErrBounds = 2u;
 constexpr int kMaxM0 = 17;    // symbols per round-0 key (bounded by the 24-byte rolling window)
 constexpr int kRun = 8;       // consecutive positions one lane rolls through in round 0
 constexpr int kTile = kRun * kWave;  // positions per wave iteration in round 0
-constexpr int kTileVecs = 14;        // 64-element vectors a wave stages per tile in a radix pass (fits 3 workgroups' LDS per CU)
+constexpr int kTileVecs = 13;        // 64-element vectors a wave stages per tile in a radix pass (fits 3 workgroups' LDS per CU)
 constexpr int kTileElems = kTileVecs * kWave;
+constexpr int kFineBits = 13;        // round 0: the top bits of the key that choose a fine bin
+constexpr int kFine = 1 << kFineBits;
+constexpr int kSortVecs = 20;        // 64-element vectors per wave in an LDS bucket sort
+constexpr int kLdsDigitBits = 8;     // digit width of the LDS bucket sort (256 bins, one per thread in the scan)
+constexpr int kLdsBins = 1 << kLdsDigitBits;
+constexpr int kMaxBuckets = 256;     // round-0 buckets per block (bucket ids are bytes in the lookup table)
+constexpr uint32_t kBucketTarget = 4224;  // elements per bucket the partition aims at (64 buckets cover 256 KiB + 1)
 
 // Per-phase time accounting (100 MHz constant clock), summed over workgroups into
 // queue[16..] as u64: 0 census, 1 round-0 digit count, 2 round-0 sort, 3 round-0 rerank,
@@ -78,13 +85,25 @@ struct PhaseClock {
 template <int NT>
 struct FwdShared {
     static constexpr int W = NT / kWave;
-    uint64_t tin[W][kTileElems];    // per-wave staging tile, elements in arrival order
-    uint16_t trk[W][kTileElems];    // per element: digit << 10 | rank among the tile's elements with that digit
-    uint16_t perm[W][kTileElems];   // tile position after grouping by digit -> arrival slot
+    static constexpr int kSortCap = NT * kSortVecs;  // largest bucket the LDS sort takes
+    struct Staging {
+        uint64_t tin[W][kTileElems];    // per-wave staging tile, elements in arrival order
+        uint16_t trk[W][kTileElems];    // per element: digit << 10 | rank among the tile's elements with that digit
+        uint16_t perm[W][kTileElems];   // tile position after grouping by digit -> arrival slot
+        uint32_t tcnt[W][kBins];        // per-wave, per-tile digit counts, then tile-local run starts
+        uint32_t tdel[W][kBins];        // per-wave: global slot of a run's first element minus its tile index
+    };
+    union {
+        Staging st;                     // radix passes through HBM
+        uint32_t fine[kFine];           // round 0: element count per fine bin
+        uint64_t lsort[kSortCap];       // one bucket being sorted inside LDS
+    } u;
+    union {
+        uint8_t lut[kFine];             // round 0: fine bin -> bucket id
+        uint32_t lhist[W * kLdsBins];   // LDS bucket sort: per-wave digit counts / offsets
+    } v;
     uint32_t hist[2][W * kBins];    // per-wave digit counts / scatter offsets, double buffered
-    uint32_t tcnt[W][kBins];        // per-wave, per-tile digit counts, then tile-local run starts
-    uint32_t tdel[W][kBins];        // per-wave: global slot of a run's first element minus its tile index
-    uint32_t sym[256];              // byte value -> code
+    uint8_t sym[256];               // byte value -> code
     uint32_t wsum[W];
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
     uint32_t blk;
@@ -126,6 +145,28 @@ __device__ __forceinline__ void scan_hist(FwdShared<NT>& sh, int sel) {
     __syncthreads();
 }
 
+// Digit of an element for one pass over key bits: ((x >> kshift) - base) >> shift, masked.
+// `base` lets a pass over a sub-range of the key space skip the bits all its keys share.
+struct KeyDigit {
+    int kshift, shift;
+    uint32_t mask;
+    uint64_t base;
+    __device__ __forceinline__ uint32_t operator()(uint64_t x) const {
+        return (uint32_t)(((x >> kshift) - base) >> shift) & mask;
+    }
+};
+
+// Digit of a round-0 element for a pass over its bucket id (looked up from the key's fine bin).
+struct BucketDigit {
+    const uint8_t* lut;
+    int fshift;  // element >> fshift = fine bin
+    int shift;
+    uint32_t mask;
+    __device__ __forceinline__ uint32_t operator()(uint64_t x) const {
+        return ((uint32_t)lut[x >> fshift] >> shift) & mask;
+    }
+};
+
 // One wave scatters the tile it has staged in LDS (tin[64 v + lane], v < nvec, in arrival
 // order; valid_of(v) tells whether this lane's element of vector v exists) by `digit`, stably:
 //   1. stable rank of every element among the tile's elements with the same digit: ballot match
@@ -134,23 +175,25 @@ __device__ __forceinline__ void scan_hist(FwdShared<NT>& sh, int sel) {
 //      starts inside the tile; the wave's global per-digit cursors advance by the counts;
 //   3. perm[run start + rank] = arrival slot: the tile's order after grouping by digit;
 //   4. the tile leaves in that order: lane i's element goes to (global cursor of its digit) +
-//      (i - run start), so consecutive lanes write consecutive slots -- whole runs (128 B on
+//      (i - run start), so consecutive lanes write consecutive slots -- whole runs (100 B on
 //      average) instead of lane-scattered 8-byte stores.
+// SHARED_CURSORS: all waves of the workgroup claim space from one cursor per digit
+// (hist[sel][digit], atomically) instead of from per-wave cursors prepared by a counting pass;
+// the result is grouped by digit but not stable across waves.
 // The NEXT pass's digit is counted per destination wave chunk on the way out.
 // All loops are rolled and everything lives in LDS, so the register footprint stays small.
-template <int NT, typename ValidOf, typename DigitOf>
-__device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, DigitOf digit_of,
-                                               uint64_t* __restrict__ dst, uint32_t m, bool has_next, int nshift,
-                                               uint32_t nmask, const Chunking& ck, FwdShared<NT>& sh, int sel,
-                                               uint32_t* err) {
+template <int NT, bool SHARED_CURSORS, typename ValidOf, typename DigitOf, typename NextOf>
+__device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, DigitOf digit_of, NextOf next_of,
+                                               uint64_t* __restrict__ dst, uint32_t m, bool has_next,
+                                               const Chunking& ck, FwdShared<NT>& sh, int sel, uint32_t* err) {
     const int lane = lane_id(), w = wave_id();
-    uint32_t* myoff = sh.hist[sel] + w * kBins;
+    uint32_t* myoff = sh.hist[sel] + (SHARED_CURSORS ? 0 : w * kBins);
     uint32_t* nhist = sh.hist[sel ^ 1];
-    uint32_t* tcnt = sh.tcnt[w];
-    uint32_t* tdel = sh.tdel[w];
-    const uint64_t* tin = sh.tin[w];
-    uint16_t* trk = sh.trk[w];
-    uint16_t* perm = sh.perm[w];
+    uint32_t* tcnt = sh.u.st.tcnt[w];
+    uint32_t* tdel = sh.u.st.tdel[w];
+    const uint64_t* tin = sh.u.st.tin[w];
+    uint16_t* trk = sh.u.st.trk[w];
+    uint16_t* perm = sh.u.st.perm[w];
     const uint64_t lt = lanemask_lt();
     tcnt[lane] = 0;
     compiler_fence();
@@ -169,11 +212,17 @@ __device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, Digit
     const uint32_t incl = wave_inclusive_scan(c);
     const uint32_t excl = incl - c;
     const uint32_t total = __shfl(incl, kWave - 1);
-    const uint32_t g0 = myoff[lane];
+    uint32_t g0;
+    if (SHARED_CURSORS) {
+        g0 = c ? atomicAdd(&myoff[lane], c) : 0u;
+    } else {
+        g0 = myoff[lane];
+        compiler_fence();
+        myoff[lane] = g0 + c;
+    }
     compiler_fence();
     tcnt[lane] = excl;
     tdel[lane] = g0 - excl;
-    myoff[lane] = g0 + c;
     compiler_fence();
     for (int v = 0; v < nvec; ++v) {
         if (valid_of(v)) {
@@ -189,7 +238,7 @@ __device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, Digit
             const uint32_t pos = tdel[digit_of(x)] + i;
             if (pos < m) {
                 dst[pos] = x;
-                if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + ((uint32_t)(x >> nshift) & nmask)], 1u);
+                if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + next_of(x)], 1u);
             } else {
                 atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
             }
@@ -200,42 +249,45 @@ __device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, Digit
 
 // One stable LSD pass over src[0..m): each wave walks its contiguous chunk one staged tile
 // (kTileVecs vectors) at a time.
-template <int NT>
+template <int NT, typename DigitOf, typename NextOf>
 __device__ __forceinline__ void radix_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
-                                           uint32_t m, const Chunking& ck, int shift, int bits, bool has_next,
-                                           int nshift, int nbits, FwdShared<NT>& sh, int sel, uint32_t* err) {
+                                           uint32_t m, const Chunking& ck, DigitOf digit_of, NextOf next_of,
+                                           bool has_next, FwdShared<NT>& sh, int sel, uint32_t* err) {
     const int lane = lane_id(), w = wave_id();
     const uint32_t lo = (uint32_t)w * ck.chunk;
     const uint32_t hi = min(lo + ck.chunk, m);
-    const uint32_t mask = (1u << bits) - 1u, nmask = (1u << nbits) - 1u;
-    uint64_t* tin = sh.tin[w];
-    auto digit_of = [=](uint64_t x) { return (uint32_t)(x >> shift) & mask; };
+    uint64_t* tin = sh.u.st.tin[w];
+    constexpr int kHalf = (kTileVecs + 1) / 2;
     for (uint32_t base = lo; base < hi; base += kTileElems) {
         const uint32_t cnt = min((uint32_t)kTileElems, hi - base);
         const int nvec = (int)((cnt + kWave - 1) / kWave);
-        // stage the tile: seven loads in flight per lane, then LDS in arrival order
+        // stage the tile: half of its loads in flight per lane at a time, then LDS in arrival order
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            uint64_t e[kTileVecs / 2];
+            uint64_t e[kHalf];
 #pragma unroll
-            for (int j = 0; j < kTileVecs / 2; ++j) {
-                const uint32_t i = (uint32_t)((h * (kTileVecs / 2) + j) * kWave + lane);
-                e[j] = i < cnt ? src[base + i] : 0ull;
+            for (int j = 0; j < kHalf; ++j) {
+                const int v = h * kHalf + j;
+                const uint32_t i = (uint32_t)(v * kWave + lane);
+                e[j] = (v < kTileVecs && i < cnt) ? src[base + i] : 0ull;
             }
 #pragma unroll
-            for (int j = 0; j < kTileVecs / 2; ++j) tin[(h * (kTileVecs / 2) + j) * kWave + lane] = e[j];
+            for (int j = 0; j < kHalf; ++j) {
+                const int v = h * kHalf + j;
+                if (v < kTileVecs) tin[v * kWave + lane] = e[j];
+            }
         }
         compiler_fence();
         auto valid_of = [=](int v) { return (uint32_t)(v * kWave + lane) < cnt; };
-        scatter_staged<NT>(nvec, valid_of, digit_of, dst, m, has_next, nshift, nmask, ck, sh, sel, err);
+        scatter_staged<NT, false>(nvec, valid_of, digit_of, next_of, dst, m, has_next, ck, sh, sel, err);
     }
 }
 
-// Sorts a[0..m) by the plan's key bits starting at bit key_shift.  On entry hist[sel] holds
-// the per-wave counts of pass `first_pass`'s digit (chunked by Chunking(m)); passes before
+// Sorts a[0..m) by the plan's key bits ((element >> key_shift) - base).  On entry hist[sel]
+// holds the per-wave counts of pass `first_pass`'s digit (chunked by Chunking(m)); passes before
 // first_pass have been done by the caller.  Returns the buffer holding the sorted elements.
 template <int NT>
-__device__ __forceinline__ uint64_t* radix_sort(uint64_t* a, uint64_t* b, uint32_t m, int key_shift,
+__device__ __forceinline__ uint64_t* radix_sort(uint64_t* a, uint64_t* b, uint32_t m, int key_shift, uint64_t base,
                                                 const DigitPlan& plan, int first_pass, FwdShared<NT>& sh,
                                                 int sel, uint32_t* err) {
     Chunking ck;
@@ -244,15 +296,141 @@ __device__ __forceinline__ uint64_t* radix_sort(uint64_t* a, uint64_t* b, uint32
         const bool has_next = p + 1 < plan.P;
         if (has_next) zero_hist<NT>(sh, sel ^ 1);
         scan_hist<NT>(sh, sel);  // its barriers also publish the zeroed next histogram
-        const int shift = key_shift + plan.shift(p);
-        const int nshift = key_shift + plan.shift(has_next ? p + 1 : p);
-        const int nbits = plan.bits(has_next ? p + 1 : p);
-        radix_pass<NT>(a, b, m, ck, shift, plan.bits(p), has_next, nshift, nbits, sh, sel, err);
+        const int pn = has_next ? p + 1 : p;
+        const KeyDigit dig{key_shift, plan.shift(p), (1u << plan.bits(p)) - 1u, base};
+        const KeyDigit nxt{key_shift, plan.shift(pn), (1u << plan.bits(pn)) - 1u, base};
+        radix_pass<NT>(a, b, m, ck, dig, nxt, has_next, sh, sel, err);
         __syncthreads();
         uint64_t* t = a; a = b; b = t;
         sel ^= 1;
     }
     return a;
+}
+
+// Counts digit_of(element) of src[0..m) per wave chunk into hist[sel] (which must be zero).
+template <int NT, typename DigitOf>
+__device__ __forceinline__ void count_digits(const uint64_t* __restrict__ src, uint32_t m, DigitOf digit_of,
+                                             FwdShared<NT>& sh, int sel) {
+    const int lane = lane_id(), w = wave_id();
+    Chunking ck;
+    ck.init(m, NT / kWave);
+    const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, m);
+    uint32_t* myhist = sh.hist[sel] + w * kBins;
+    for (uint32_t k = lo + lane; k < hi; k += kWave) atomicAdd(&myhist[digit_of(src[k])], 1u);
+}
+
+// Lanes of the wave whose digit equals mine; `bits` (wave-uniform, <= 8) is the digit width.
+__device__ __forceinline__ uint64_t match_digit_n(uint32_t d, int bits, bool valid) {
+    switch (bits) {
+        case 8: return match_digit<8>(d, valid);
+        case 7: return match_digit<7>(d, valid);
+        case 6: return match_digit<6>(d, valid);
+        case 5: return match_digit<5>(d, valid);
+        default: break;
+    }
+    return match_digit<4>(d, valid);
+}
+
+// Sorts the bucket g[0..cnt), cnt <= kSortCap, by ((element >> kshift) - base), which has at
+// most `bits` bits, entirely inside LDS and writes it back in place.  LSD passes with 8-bit
+// digits; every lane keeps its kSortVecs elements in registers during a pass (wave w owns the
+// contiguous slice [w*per, (w+1)*per) of the current order), so one LDS buffer serves as both
+// source and destination: ranks first, barrier, then all lanes store.
+template <int NT>
+__device__ __forceinline__ void lds_sort_bucket(uint64_t* __restrict__ g, uint32_t cnt, int kshift, uint64_t base,
+                                                int bits, FwdShared<NT>& sh) {
+    static_assert(NT == kLdsBins, "the offset scan gives one digit to each thread");
+    constexpr int W = NT / kWave, V = kSortVecs;
+    if (bits <= 0) return;  // all keys equal
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t per = (cnt + (uint32_t)NT - 1u) / (uint32_t)NT * (uint32_t)kWave;  // elements per wave
+    const int nv = (int)(per / kWave);
+    const uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * per));
+    const uint64_t lt = lanemask_lt();
+    uint64_t e[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        e[v] = 0;
+        const uint32_t i = wb + (uint32_t)(v * kWave + lane);
+        if (v < nv && i < cnt) e[v] = g[i];
+    }
+    const int P = (bits + kLdsDigitBits - 1) / kLdsDigitBits;
+    const int db = (bits + P - 1) / P;
+    const uint32_t mask = (1u << db) - 1u;
+    uint32_t* lh = sh.v.lhist + w * kLdsBins;
+    uint64_t* ls = sh.u.lsort;
+    for (int p = 0; p < P; ++p) {
+        const int shift = p * db;
+        for (int i = tid; i < W * kLdsBins; i += NT) sh.v.lhist[i] = 0;
+        __syncthreads();
+        uint32_t r[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            r[v] = 0;
+            if (v < nv) {  // wave-uniform
+                const bool ok = wb + (uint32_t)(v * kWave + lane) < cnt;
+                const uint32_t d = (uint32_t)(((e[v] >> kshift) - base) >> shift) & mask;
+                const uint64_t peers = match_digit_n(d, db, ok);
+                const uint32_t rk = __popcll(peers & lt);
+                const uint32_t b0 = lh[ok ? d : 0u];
+                compiler_fence();
+                if (ok && rk == 0) lh[d] = b0 + (uint32_t)__popcll(peers);
+                compiler_fence();
+                r[v] = (d << 16) | (b0 + rk);
+            }
+        }
+        __syncthreads();
+        {   // offsets: exclusive scan in (digit major, wave minor) order; thread t owns digit t
+            uint32_t c[W], tot = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                c[i] = sh.v.lhist[i * kLdsBins + tid];
+                tot += c[i];
+            }
+            uint32_t total;
+            uint32_t run = block_exclusive_scan<NT>(tot, sh.wsum, total);
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                sh.v.lhist[i * kLdsBins + tid] = run;
+                run += c[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (v < nv && wb + (uint32_t)(v * kWave + lane) < cnt) ls[lh[r[v] >> 16] + (r[v] & 0xFFFFu)] = e[v];
+        }
+        __syncthreads();
+        if (p + 1 < P) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const uint32_t i = wb + (uint32_t)(v * kWave + lane);
+                if (v < nv && i < cnt) e[v] = ls[i];
+            }
+        }
+    }
+    for (uint32_t i = tid; i < cnt; i += NT) g[i] = ls[i];
+    __syncthreads();
+}
+
+// Sorts the sub-range a[0..cnt) (too large for LDS) through HBM with b[0..cnt) as the other
+// buffer; the result always ends in a.
+template <int NT>
+__device__ __forceinline__ void sort_range_global(uint64_t* a, uint64_t* b, uint32_t cnt, int kshift, uint64_t base,
+                                                  int bits, FwdShared<NT>& sh, uint32_t* err) {
+    if (bits <= 0) return;
+    DigitPlan plan;
+    plan.init(bits);
+    zero_hist<NT>(sh, 0);
+    __syncthreads();
+    const KeyDigit d0{kshift, plan.shift(0), (1u << plan.bits(0)) - 1u, base};
+    count_digits<NT>(a, cnt, d0, sh, 0);
+    __syncthreads();
+    uint64_t* sorted = radix_sort<NT>(a, b, cnt, kshift, base, plan, 0, sh, 0, err);
+    if (sorted != a) {
+        for (uint32_t i = threadIdx.x; i < cnt; i += NT) a[i] = b[i];
+    }
+    __syncthreads();
 }
 
 // ---- round 0: rolling packed keys -------------------------------------------------------------
@@ -264,6 +442,7 @@ struct Round0 {
     uint32_t dcode;        // code of the delimiter
     uint32_t delim;        // the delimiter byte itself
     int m0, sbits, ibits;
+    int fshift;            // key >> fshift = fine bin
     uint64_t kmask;        // m0*sbits low bits
 };
 
@@ -279,14 +458,17 @@ __device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* p, const u
 // Round-0 element: key << (ibits + 8) | preceding byte << ibits | position.  Carrying the byte
 // that precedes the suffix through the sort lets every suffix that is already unique after
 // round 0 emit its output byte with a coalesced store (no gather, no rank array).
-// MODE 0: count pass 0's digit of every element into hist[sel] (per wave).
-// MODE 1: generate the elements again and run pass 0 on them (rank + scatter into dst).
+// MODE 0: count the elements per fine bin (top bits of the key) into u.fine.
+// MODE 1: generate the elements again and partition them by bucket id digit (`dig`; `nxt` is
+//         the digit of a following pass, counted on the way out when has_next) into dst, the
+//         waves sharing one cursor per digit in hist[sel].
 // Lane l of a wave tile rolls through positions q0 .. q0+7 (q0 = tile + 8 l): it reads the 24
 // bytes that start at q0 + m0 - 17, pushes one symbol code per step into a shift register
 // and, from step 16 on, the register holds the key of position q0 + (step - 16).
 template <int NT, int MODE>
-__device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& plan, uint64_t* __restrict__ dst,
-                                             FwdShared<NT>& sh, int sel, uint32_t* err) {
+__device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit& dig, const BucketDigit& nxt,
+                                             bool has_next, uint64_t* __restrict__ dst, FwdShared<NT>& sh, int sel,
+                                             uint32_t* err) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
     uint32_t chunk0 = (r.n + (uint32_t)W - 1u) / (uint32_t)W;
@@ -295,12 +477,7 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
     const uint32_t hi = min(lo + chunk0, r.n);
     Chunking ck;
     ck.init(r.n, W);
-    uint32_t* myoff = sh.hist[sel] + w * kBins;
-    const uint32_t dmask = (1u << plan.bits(0)) - 1u;
-    const bool has_next = plan.P > 1;
     const int kshift = r.ibits + 8;
-    const int nshift = kshift + plan.shift(has_next ? 1 : 0);
-    const uint32_t nmask = (1u << plan.bits(has_next ? 1 : 0)) - 1u;
     const int lead = kMaxM0 - r.m0;  // steps whose symbols would be shifted out anyway
     for (uint32_t tile = lo; tile < hi; tile += kTile) {
         const uint32_t q0 = tile + (uint32_t)(kRun * lane);
@@ -335,7 +512,7 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
             if (t >= lead) {  // wave-uniform
                 const uint32_t pos = q0 + (uint32_t)(t - lead);  // = wstart + t, never negative here
                 const uint32_t byte = (win[t >> 2] >> (8 * (t & 3))) & 255u;
-                uint32_t c = sh.sym[byte];
+                uint32_t c = (uint32_t)sh.sym[byte] + 1u;
                 if (pos >= r.len) c = (pos == r.len) ? r.dcode : 0u;
                 key = ((key << r.sbits) | c) & r.kmask;
             }
@@ -344,7 +521,7 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
                 const uint32_t pe = q0 + (uint32_t)j;
                 const bool valid = pe < hi;
                 if (MODE == 0) {
-                    if (valid) atomicAdd(&myoff[(uint32_t)key & dmask], 1u);
+                    if (valid) atomicAdd(&sh.u.fine[(uint32_t)(key >> r.fshift)], 1u);
                 } else {
                     uint32_t prev = (prevw[j >> 2] >> (8 * (j & 3))) & 255u;
                     if (pe == 0) prev = r.delim;  // the row of suffix 0 carries the delimiter (src/bwt.cpp:115-116)
@@ -354,16 +531,87 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const DigitPlan& p
             }
         }
         if (MODE == 1) {
-            // pass 0 needs no particular order among equal digits, so the lane-run layout is fine
-            uint64_t* tin = sh.tin[w];
+            // the partition needs no particular order inside a bucket, so the lane-run layout is fine
+            uint64_t* tin = sh.u.st.tin[w];
 #pragma unroll
             for (int j = 0; j < kRun; ++j) tin[j * kWave + lane] = el[j];
             compiler_fence();
-            auto digit_of = [=](uint64_t x) { return (uint32_t)(x >> kshift) & dmask; };
             auto valid_of = [=](int v) { return (valid_bits >> v) & 1u; };
-            scatter_staged<NT>(kRun, valid_of, digit_of, dst, r.n, has_next, nshift, nmask, ck, sh, sel, err);
+            scatter_staged<NT, true>(kRun, valid_of, dig, nxt, dst, r.n, has_next, ck, sh, sel, err);
         }
     }
+}
+
+// Where the round-0 buckets of a block start and which fine bins they cover; lives in the
+// block's rank array until the ranks are written.  start[k+1] - start[k] = size of bucket k;
+// flo[k] .. flo[k+1]-1 = the fine bins a non-empty bucket k may hold.
+struct BucketDir {
+    uint32_t* start;   // [nb + 1]
+    uint32_t* flo;     // [nb + 1]
+    uint32_t nb;       // number of bucket ids (some may be empty)
+};
+
+// Groups the fine bins (u.fine counts) into buckets of about `target` elements: a bin goes to
+// bucket floor(first slot of the bin / target), so buckets are contiguous key ranges of at most
+// target + (largest bin) elements, in key order.  Fills v.lut and the directory.
+template <int NT>
+__device__ __forceinline__ void assign_buckets(FwdShared<NT>& sh, uint32_t n, uint32_t target, int fbits,
+                                               BucketDir& dir) {
+    constexpr int PER = kFine / NT;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t nb = (n - 1u) / target + 1u;
+    dir.nb = nb;
+    uint32_t* tstart = sh.hist[0];            // temporary: first slot per bucket id
+    uint32_t* tflo = sh.hist[0] + kMaxBuckets;  // temporary: first fine bin per bucket id
+    static_assert(2 * kMaxBuckets <= 2 * (NT / kWave) * kBins, "bucket temporaries fit the two histograms");
+    for (int k = tid; k < 2 * kMaxBuckets; k += NT) sh.hist[0][k] = 0xFFFFFFFFu;
+    uint32_t sum = 0;
+#pragma unroll 4
+    for (int j = 0; j < PER; ++j) sum += sh.u.fine[tid * PER + j];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<NT>(sum, sh.wsum, total);  // its barriers publish the initialised temporaries
+    Chunking dv;  // division by target
+    dv.chunk = target;
+    dv.magic = 0xFFFFFFFFu / target + 1u;
+#pragma unroll 1
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t f = (uint32_t)(tid * PER + j);
+        const uint32_t c = sh.u.fine[f];
+        uint32_t id = 0;
+        if (c) {
+            id = dv.wave_of(run);
+            atomicMin(&tstart[id], run);
+            atomicMin(&tflo[id], f);
+        }
+        sh.v.lut[f] = (uint8_t)id;
+        run += c;
+    }
+    __syncthreads();
+    if (w == 0) {  // suffix minima, so an empty bucket id reads as an empty range
+        uint32_t cs = n, cf = 1u << fbits;
+        for (int c = (int)(nb / kWave); c >= 0; --c) {
+            const uint32_t k = (uint32_t)(c * kWave + lane);
+            uint32_t sv = k < nb ? tstart[k] : 0xFFFFFFFFu;
+            uint32_t fv = k < nb ? tflo[k] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t ys = __shfl_down(sv, o), yf = __shfl_down(fv, o);
+                if (lane + o < kWave) {
+                    sv = min(sv, ys);
+                    fv = min(fv, yf);
+                }
+            }
+            sv = min(sv, cs);
+            fv = min(fv, cf);
+            if (k <= nb) {
+                dir.start[k] = sv;
+                dir.flo[k] = fv;
+            }
+            cs = __shfl(sv, 0);
+            cf = __shfl(fv, 0);
+        }
+    }
+    __syncthreads();
 }
 
 struct RunFlags {
@@ -525,12 +773,12 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
 // Rank of suffix j by its first m0 symbols = number of round-0 elements with a smaller key:
 // binary search in the sorted round-0 array (used while the rank array holds survivors only).
 __device__ __forceinline__ uint32_t rank_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
-                                                   const uint32_t* sym, uint32_t j) {
+                                                   const uint8_t* sym, uint32_t j) {
     uint64_t key = 0;
     for (int t = 0; t < r.m0; ++t) {
         const uint32_t p = j + (uint32_t)t;
         uint32_t c = 0;
-        if (p < r.len) c = sym[r.s[p]];
+        if (p < r.len) c = (uint32_t)sym[r.s[p]] + 1u;
         else if (p == r.len) c = r.dcode;
         key = (key << r.sbits) | c;
     }
@@ -567,43 +815,91 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     const uint32_t present = tid < 256 ? sh.sym[tid] : 0;
     uint32_t sigma;
     const uint32_t below = block_exclusive_scan<NT>(present, sh.wsum, sigma);
-    if (tid < 256) sh.sym[tid] = present ? below + 1 : 0;
+    if (tid < 256) sh.sym[tid] = (uint8_t)below;  // code - 1 (codes run 1..sigma; 0 = past the end)
     const int sbits = bit_length(sigma);
     const int ibits = bit_length(n - 1);
     int m0 = (2 * ibits) / sbits;
     const int m0cap = min((64 - 8 - ibits) / sbits, kMaxM0);
     if (m0 > m0cap) m0 = m0cap;
     if (m0 < 1) m0 = 1;
-    DigitPlan plan;
-    plan.init(m0 * sbits);
-    zero_hist<NT>(sh, 0);
+    const int kbits = m0 * sbits;
+    const int fbits = min(kbits, kFineBits);
+    for (int i = tid; i < kFine; i += NT) sh.u.fine[i] = 0;
     __syncthreads();
     pc.lap(0);
 
-    // ---- 1. round 0: packed m0-symbol keys, generated straight into the first pass ----------
+    // ---- 1. round 0: sort all suffixes by their first m0 symbols ------------------------------
+    // count per fine bin -> buckets of contiguous key ranges -> partition into the buckets
+    // (keys generated on the fly both times) -> every bucket sorted inside LDS.
     Round0 r0;
     r0.s = s;
     r0.g_lo = a.in;
     r0.g_hi = a.in + a.total_len;
     r0.len = len;
     r0.n = n;
-    r0.dcode = sh.sym[delim];
+    r0.dcode = (uint32_t)sh.sym[delim] + 1u;
     r0.delim = delim;
     r0.m0 = m0;
     r0.sbits = sbits;
     r0.ibits = ibits;
-    r0.kmask = (1ull << (m0 * sbits)) - 1ull;
+    r0.fshift = kbits - fbits;
+    r0.kmask = (1ull << kbits) - 1ull;
     const int kshift0 = ibits + 8;
-    round0_sweep<NT, 0>(r0, plan, nullptr, sh, 0, &queue[1]);
+    BucketDigit dig{sh.v.lut, kshift0 + r0.fshift, 0, 0u}, dig2 = dig;
+    round0_sweep<NT, 0>(r0, dig, dig2, false, nullptr, sh, 0, &queue[1]);
     __syncthreads();
     pc.lap(1);
-    if (plan.P > 1) zero_hist<NT>(sh, 1);
-    scan_hist<NT>(sh, 0);
-    round0_sweep<NT, 1>(r0, plan, bufA, sh, 0, &queue[1]);
+    BucketDir dir;
+    dir.start = rank;
+    const uint32_t target = max(kBucketTarget, (n + (uint32_t)kMaxBuckets - 1u) / (uint32_t)kMaxBuckets);
+    dir.flo = rank + ((n - 1u) / target + 2u);
+    assign_buckets<NT>(sh, n, target, fbits, dir);
+    const bool two_pass = dir.nb > (uint32_t)kBins;
+    const int b1 = two_pass ? 4 : kMaxDigitBits;
+    dig.mask = (1u << b1) - 1u;
+    dig2.shift = b1;
+    dig2.mask = (1u << kMaxDigitBits) - 1u;
+    // shared cursors of the partition pass: where each digit's elements start
+    zero_hist<NT>(sh, 1);
+    if (w == 0) {
+        uint32_t c = 0;
+        if (!two_pass) {
+            c = (uint32_t)lane < dir.nb ? dir.start[lane + 1] - dir.start[lane] : 0u;
+        } else if (lane < 16) {
+            for (uint32_t k = (uint32_t)lane; k < dir.nb; k += 16u) c += dir.start[k + 1] - dir.start[k];
+        }
+        const uint32_t incl = wave_inclusive_scan(c);
+        sh.hist[0][lane] = incl - c;
+    }
     __syncthreads();
-    uint64_t* const sorted0 = radix_sort<NT>(bufA, bufB, n, kshift0, plan, 1, sh, 1, &queue[1]);
-    uint64_t* const spare = (sorted0 == bufA) ? bufB : bufA;
+    round0_sweep<NT, 1>(r0, dig, dig2, two_pass, bufA, sh, 0, &queue[1]);
+    __syncthreads();
+    uint64_t* sorted0 = bufA;
+    uint64_t* spare = bufB;
+    if (two_pass) {
+        Chunking ck;
+        ck.init(n, W);
+        scan_hist<NT>(sh, 1);
+        radix_pass<NT>(bufA, bufB, n, ck, dig2, dig2, false, sh, 1, &queue[1]);
+        __syncthreads();
+        sorted0 = bufB;
+        spare = bufA;
+    }
     pc.lap(2);
+    for (uint32_t k = 0; k < dir.nb; ++k) {
+        const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
+        if (cnt == 0) continue;  // workgroup-uniform
+        const uint32_t f0 = dir.flo[k], f1 = dir.flo[k + 1];
+        const uint64_t base = (uint64_t)f0 << r0.fshift;
+        const int bits = r0.fshift + bit_length(f1 - f0 - 1u);
+        if (cnt <= (uint32_t)FwdShared<NT>::kSortCap) {
+            lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh);
+            pc.lap(10);
+        } else {
+            sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
+            pc.lap(11);
+        }
+    }
     // element layout for rounds >= 1: g | r2 | i, where r2 = rank[i+h] + 1, or 0 when the
     // suffix ends exactly at i+h (possible only if the delimiter also occurs inside the
     // block): "past the end" orders before every real rank, as in src/bwt.cpp:77-79
@@ -616,6 +912,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     io.delim = delim;
     uint32_t m, G;
     bool full;
+    __syncthreads();  // the bucket directory (in the rank array) is dead from here on
     rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, false, sh, m, G, full);
     pc.lap(3);
 
@@ -631,6 +928,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             break;
         }
         const int gbits = max(1, bit_length(G - 1));
+        DigitPlan plan;
         plan.init(rbits + gbits);
         zero_hist<NT>(sh, 0);
         __syncthreads();
@@ -656,7 +954,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         }
         __syncthreads();
         pc.lap(4);
-        uint64_t* sorted = radix_sort<NT>(alt, cur, m, ibits, plan, 0, sh, 0, &queue[1]);
+        uint64_t* sorted = radix_sort<NT>(alt, cur, m, ibits, 0ull, plan, 0, sh, 0, &queue[1]);
         pc.lap(5);
         uint64_t* other = (sorted == alt) ? cur : alt;
         uint32_t m2, G2;
@@ -685,7 +983,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void bwt_forward_kernel(FwdArgs a) {
+__global__ __launch_bounds__(NT, 3) void bwt_forward_kernel(FwdArgs a) {
     __shared__ FwdShared<NT> sh;
     uint64_t* bufA = reinterpret_cast<uint64_t*>(a.ws + (uint64_t)blockIdx.x * a.ws_stride);
     uint64_t* bufB = bufA + a.ncap;
