@@ -58,6 +58,7 @@ constexpr int kSortVecs = 20;        // 64-element vectors per wave in an LDS bu
 constexpr int kLdsDigitBits = 8;     // digit width of the LDS bucket sort (256 bins, one per thread in the scan)
 constexpr int kLdsBins = 1 << kLdsDigitBits;
 constexpr int kMaxBuckets = 256;     // round-0 buckets per block (bucket ids are bytes in the lookup table)
+constexpr size_t kBucketDirBytes = 2 * (kMaxBuckets + 1) * sizeof(uint32_t);  // bucket directory after the rank array
 constexpr uint32_t kBucketTarget = 4224;  // elements per bucket the partition aims at (64 buckets cover 256 KiB + 1)
 
 // Per-phase time accounting (100 MHz constant clock), summed over workgroups into
@@ -332,7 +333,8 @@ __device__ __forceinline__ uint64_t match_digit_n(uint32_t d, int bits, bool val
 }
 
 // Sorts the bucket g[0..cnt), cnt <= kSortCap, by ((element >> kshift) - base), which has at
-// most `bits` bits, entirely inside LDS and writes it back in place.  LSD passes with 8-bit
+// most `bits` bits, entirely inside LDS and leaves it in u.lsort[0..cnt) (published by a
+// barrier); the caller writes it back.  LSD passes with 8-bit
 // digits; every lane keeps its kSortVecs elements in registers during a pass (wave w owns the
 // contiguous slice [w*per, (w+1)*per) of the current order), so one LDS buffer serves as both
 // source and destination: ranks first, barrier, then all lanes store.
@@ -341,8 +343,12 @@ __device__ __forceinline__ void lds_sort_bucket(uint64_t* __restrict__ g, uint32
                                                 int bits, FwdShared<NT>& sh) {
     static_assert(NT == kLdsBins, "the offset scan gives one digit to each thread");
     constexpr int W = NT / kWave, V = kSortVecs;
-    if (bits <= 0) return;  // all keys equal
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if (bits <= 0) {  // all keys equal
+        for (uint32_t i = tid; i < cnt; i += NT) sh.u.lsort[i] = g[i];
+        __syncthreads();
+        return;
+    }
     const uint32_t per = (cnt + (uint32_t)NT - 1u) / (uint32_t)NT * (uint32_t)kWave;  // elements per wave
     const int nv = (int)(per / kWave);
     const uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * per));
@@ -409,7 +415,12 @@ __device__ __forceinline__ void lds_sort_bucket(uint64_t* __restrict__ g, uint32
             }
         }
     }
-    for (uint32_t i = tid; i < cnt; i += NT) g[i] = ls[i];
+}
+
+// Writes a bucket sorted in LDS back to g[0..cnt).
+template <int NT>
+__device__ __forceinline__ void store_bucket(uint64_t* __restrict__ g, uint32_t cnt, FwdShared<NT>& sh) {
+    for (uint32_t i = threadIdx.x; i < cnt; i += NT) g[i] = sh.u.lsort[i];
     __syncthreads();
 }
 
@@ -770,6 +781,92 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
     __syncthreads();
 }
 
+// Round-0 rerank of one bucket while it is still sorted in LDS (u.lsort[0..cnt), global
+// sorted positions s0 .. s0+cnt-1; a bucket is a key range, so runs never cross its ends):
+// writes the bucket back to g, stores the output byte of every suffix that is alone in its run,
+// and for the others writes rank (= global position of the run's first element) and appends
+// (dense group id << gshift | index) to nxt.  m_tot / g_tot are the running survivor and group
+// counts of the block and are advanced.
+template <int NT>
+__device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t s0, uint32_t cnt,
+                                              uint64_t* __restrict__ nxt, uint32_t* __restrict__ rank,
+                                              uint8_t* __restrict__ out, int ibits, int kshift, int gshift,
+                                              FwdShared<NT>& sh, uint32_t& m_tot, uint32_t& g_tot) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    const uint64_t* ls = sh.u.lsort;
+    Chunking ck;
+    ck.init(cnt, W);
+    const uint32_t lo = (uint32_t)w * ck.chunk;
+    const uint32_t hi = min(lo + ck.chunk, cnt);
+    const uint64_t lt = lanemask_lt(), le = lanemask_le();
+    const uint64_t imask = (1ull << ibits) - 1ull;
+    auto flags = [&](uint32_t k, uint64_t& ec, bool& head, bool& tail) {
+        const bool valid = k < hi;
+        ec = valid ? ls[k] : 0ull;
+        const uint64_t key = ec >> kshift;
+        const uint64_t kp = (valid && k > 0) ? ls[k - 1] >> kshift : ~0ull;
+        const uint64_t kn = (valid && k + 1 < cnt) ? ls[k + 1] >> kshift : ~0ull;
+        head = valid && kp != key;
+        tail = valid && kn != key;
+        return valid;
+    };
+    uint32_t cA = 0, cG = 0, lH = 0;
+    for (uint32_t base = lo; base < hi; base += kWave) {
+        uint64_t ec;
+        bool head, tail;
+        const bool valid = flags(base + lane, ec, head, tail);
+        const uint64_t H = __ballot(head);
+        cA += __popcll(__ballot(valid && !(head && tail)));
+        cG += __popcll(__ballot(head && !tail));
+        if (H) lH = base + 63u - (uint32_t)__clzll(H);
+    }
+    if (lane == 0) {
+        sh.cntA[w] = cA;
+        sh.cntG[w] = cG;
+        sh.lastH[w] = lH;
+    }
+    __syncthreads();
+    uint32_t baseA = m_tot, baseG = g_tot, carryH = 0, totA = 0, totG = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t ca = sh.cntA[i], cg = sh.cntG[i];
+        if (i < w) {
+            baseA += ca;
+            baseG += cg;
+            carryH = max(carryH, sh.lastH[i]);
+        }
+        totA += ca;
+        totG += cg;
+    }
+    for (uint32_t base = lo; base < hi; base += kWave) {
+        uint64_t ec;
+        bool head, tail;
+        const bool valid = flags(base + lane, ec, head, tail);
+        const uint64_t H = __ballot(head);
+        const uint64_t hm = H & le;
+        const uint32_t khead = hm ? base + 63u - (uint32_t)__clzll(hm) : carryH;
+        if (H) carryH = base + 63u - (uint32_t)__clzll(H);
+        const bool single = head && tail;
+        const bool act = valid && !single;
+        const uint64_t A = __ballot(act), NS = __ballot(head && !tail);
+        const uint32_t idx = (uint32_t)(ec & imask);
+        if (valid) g[base + lane] = ec;
+        if (single) out[s0 + base + lane] = (uint8_t)(ec >> ibits);
+        if (act) {
+            rank[idx] = s0 + khead;
+            const uint32_t pos = baseA + __popcll(A & lt);
+            const uint32_t gid = baseG + __popcll(NS & le) - 1u;
+            nxt[pos] = ((uint64_t)gid << gshift) | idx;
+        }
+        baseA += __popcll(A);
+        baseG += __popcll(NS);
+    }
+    m_tot += totA;
+    g_tot += totG;
+    __syncthreads();  // cntA/cntG/lastH and the LDS bucket are free again
+}
+
 // Rank of suffix j by its first m0 symbols = number of round-0 elements with a smaller key:
 // binary search in the sorted round-0 array (used while the rank array holds survivors only).
 __device__ __forceinline__ uint32_t rank_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
@@ -850,9 +947,9 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     __syncthreads();
     pc.lap(1);
     BucketDir dir;
-    dir.start = rank;
+    dir.start = rank + a.ncap;
     const uint32_t target = max(kBucketTarget, (n + (uint32_t)kMaxBuckets - 1u) / (uint32_t)kMaxBuckets);
-    dir.flo = rank + ((n - 1u) / target + 2u);
+    dir.flo = dir.start + (kMaxBuckets + 1);
     assign_buckets<NT>(sh, n, target, fbits, dir);
     const bool two_pass = dir.nb > (uint32_t)kBins;
     const int b1 = two_pass ? 4 : kMaxDigitBits;
@@ -886,6 +983,16 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         spare = bufA;
     }
     pc.lap(2);
+    // element layout for rounds >= 1: g | r2 | i, where r2 = rank[i+h] + 1, or 0 when the
+    // suffix ends exactly at i+h (possible only if the delimiter also occurs inside the
+    // block): "past the end" orders before every real rank, as in src/bwt.cpp:77-79
+    const int rbits = bit_length(n);
+    const int gshift = ibits + rbits;
+    // When every bucket fits LDS the rerank is done on the sorted bucket while it is still
+    // there (survivor ranks only); otherwise, or when many suffixes survive, a separate sweep does it.
+    bool fused = true;
+    for (uint32_t k = 0; k < dir.nb; ++k) fused = fused && dir.start[k + 1] - dir.start[k] <= (uint32_t)FwdShared<NT>::kSortCap;
+    uint32_t m = 0, G = 0;
     for (uint32_t k = 0; k < dir.nb; ++k) {
         const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
         if (cnt == 0) continue;  // workgroup-uniform
@@ -894,26 +1001,22 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         const int bits = r0.fshift + bit_length(f1 - f0 - 1u);
         if (cnt <= (uint32_t)FwdShared<NT>::kSortCap) {
             lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh);
+            if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, sh, m, G);
+            else store_bucket<NT>(sorted0 + s0, cnt, sh);
             pc.lap(10);
         } else {
             sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
             pc.lap(11);
         }
     }
-    // element layout for rounds >= 1: g | r2 | i, where r2 = rank[i+h] + 1, or 0 when the
-    // suffix ends exactly at i+h (possible only if the delimiter also occurs inside the
-    // block): "past the end" orders before every real rank, as in src/bwt.cpp:77-79
-    const int rbits = bit_length(n);
-    const int gshift = ibits + rbits;
     BlockIO io;
     io.s = s;
     io.out = out;
     io.n = n;
     io.delim = delim;
-    uint32_t m, G;
-    bool full;
-    __syncthreads();  // the bucket directory (in the rank array) is dead from here on
-    rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, false, sh, m, G, full);
+    bool full = false;
+    __syncthreads();
+    if (!fused || m > n / 16u) rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, false, sh, m, G, full);
     pc.lap(3);
 
     // ---- 2. doubling rounds over the survivors -----------------------------------

@@ -98,7 +98,7 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     g.nblocks = (total_len + block_size - 1) / block_size;
     const size_t longest = std::min(total_len, block_size);
     g.ncap = (uint32_t)round_up(longest + 1, 64);
-    g.stride = round_up((size_t)g.ncap * 20, 256);
+    g.stride = round_up((size_t)g.ncap * 20 + bwtgpu::kBucketDirBytes, 256);
     const size_t max_wgs = (size_t)d.cus * (size_t)d.fwd_wgs_per_cu;
     g.grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
     g.bytes = kHeaderBytes + g.stride * g.grid;
