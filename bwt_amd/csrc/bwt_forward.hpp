@@ -54,12 +54,11 @@ constexpr int kTileVecs = 13;        // 64-element vectors a wave stages per til
 constexpr int kTileElems = kTileVecs * kWave;
 constexpr int kFineBits = 13;        // round 0: the top bits of the key that choose a fine bin
 constexpr int kFine = 1 << kFineBits;
-constexpr int kSortVecs = 20;        // 64-element vectors per wave in an LDS bucket sort
-constexpr int kLdsDigitBits = 8;     // digit width of the LDS bucket sort (256 bins, one per thread in the scan)
-constexpr int kLdsBins = 1 << kLdsDigitBits;
+constexpr int kSortVecs = 19;        // elements per thread in an LDS bucket sort (odd, see lds_sort_bucket)
+constexpr int kLdsDigitBits = 4;     // digit width of the LDS bucket sort
 constexpr int kMaxBuckets = 256;     // round-0 buckets per block (bucket ids are bytes in the lookup table)
 constexpr size_t kBucketDirBytes = 2 * (kMaxBuckets + 1) * sizeof(uint32_t);  // bucket directory after the rank array
-constexpr uint32_t kBucketTarget = 4224;  // elements per bucket the partition aims at (64 buckets cover 256 KiB + 1)
+constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition aims at (64 buckets cover 256 KiB + 1)
 
 // Per-phase time accounting (100 MHz constant clock), summed over workgroups into
 // queue[16..] as u64: 0 census, 1 round-0 digit count, 2 round-0 sort, 3 round-0 rerank,
@@ -101,7 +100,7 @@ struct FwdShared {
     } u;
     union {
         uint8_t lut[kFine];             // round 0: fine bin -> bucket id
-        uint32_t lhist[W * kLdsBins];   // LDS bucket sort: per-wave digit counts / offsets
+        uint32_t cw[8 * NT];            // LDS bucket sort: 16 counters of 16 bits per thread
     } v;
     uint32_t hist[2][W * kBins];    // per-wave digit counts / scatter offsets, double buffered
     uint8_t sym[256];               // byte value -> code
@@ -320,101 +319,93 @@ __device__ __forceinline__ void count_digits(const uint64_t* __restrict__ src, u
     for (uint32_t k = lo + lane; k < hi; k += kWave) atomicAdd(&myhist[digit_of(src[k])], 1u);
 }
 
-// Lanes of the wave whose digit equals mine; `bits` (wave-uniform, <= 8) is the digit width.
-__device__ __forceinline__ uint64_t match_digit_n(uint32_t d, int bits, bool valid) {
-    switch (bits) {
-        case 8: return match_digit<8>(d, valid);
-        case 7: return match_digit<7>(d, valid);
-        case 6: return match_digit<6>(d, valid);
-        case 5: return match_digit<5>(d, valid);
-        default: break;
-    }
-    return match_digit<4>(d, valid);
-}
-
 // Sorts the bucket g[0..cnt), cnt <= kSortCap, by ((element >> kshift) - base), which has at
 // most `bits` bits, entirely inside LDS and leaves it in u.lsort[0..cnt) (published by a
-// barrier); the caller writes it back.  LSD passes with 8-bit
-// digits; every lane keeps its kSortVecs elements in registers during a pass (wave w owns the
-// contiguous slice [w*per, (w+1)*per) of the current order), so one LDS buffer serves as both
-// source and destination: ranks first, barrier, then all lanes store.
+// barrier); the caller writes it back.
+// LSD passes with 4-bit digits.  The bucket is padded with all-ones elements to a multiple of
+// kSortVecs; thread t owns the kSortVecs consecutive positions that start at kSortVecs * t
+// (an odd stride, so a wave's 8-byte LDS reads spread over all banks) and keeps them in
+// registers during a pass; threads past the padded end idle.  Ranking uses one private
+// counter per (digit, thread): an LDS add-with-return per element gives its rank among the
+// thread's elements with that digit, an exclusive scan of the counters in (digit, thread)
+// order gives where each (digit, thread) run starts.  Counters are 16 bits wide, digits d and
+// d+8 share a word and thread t's words sit at row*NT + t, so the lanes of a wave always hit
+// different banks.  The padding has the largest digit in every pass and starts out behind all
+// real elements, so stability keeps it behind them.
 template <int NT>
-__device__ __forceinline__ void lds_sort_bucket(uint64_t* __restrict__ g, uint32_t cnt, int kshift, uint64_t base,
-                                                int bits, FwdShared<NT>& sh) {
-    static_assert(NT == kLdsBins, "the offset scan gives one digit to each thread");
-    constexpr int W = NT / kWave, V = kSortVecs;
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+__device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, uint32_t cnt, int kshift,
+                                                uint64_t base, int bits, FwdShared<NT>& sh) {
+    constexpr int V = kSortVecs;
+    const int tid = threadIdx.x;
+    uint64_t* ls = sh.u.lsort;
     if (bits <= 0) {  // all keys equal
-        for (uint32_t i = tid; i < cnt; i += NT) sh.u.lsort[i] = g[i];
+        for (uint32_t i = tid; i < cnt; i += NT) ls[i] = g[i];
         __syncthreads();
         return;
     }
-    const uint32_t per = (cnt + (uint32_t)NT - 1u) / (uint32_t)NT * (uint32_t)kWave;  // elements per wave
-    const int nv = (int)(per / kWave);
-    const uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w * per));
-    const uint64_t lt = lanemask_lt();
-    uint64_t e[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-        e[v] = 0;
-        const uint32_t i = wb + (uint32_t)(v * kWave + lane);
-        if (v < nv && i < cnt) e[v] = g[i];
-    }
+    const uint32_t nthr = (cnt + (uint32_t)V - 1u) / (uint32_t)V;  // threads that own elements
+    const uint32_t cntp = nthr * (uint32_t)V;
+    const bool active = (uint32_t)tid < nthr;
+    const uint64_t bsub = base << kshift;
+    for (uint32_t i = tid; i < cntp; i += NT) ls[i] = i < cnt ? g[i] - bsub : ~0ull;
     const int P = (bits + kLdsDigitBits - 1) / kLdsDigitBits;
     const int db = (bits + P - 1) / P;
     const uint32_t mask = (1u << db) - 1u;
-    uint32_t* lh = sh.v.lhist + w * kLdsBins;
-    uint64_t* ls = sh.u.lsort;
+    uint32_t* cw = sh.v.cw;
+    uint32_t* mycw = cw + tid;
+    const uint64_t* mine = ls + (uint32_t)tid * (uint32_t)V;
     for (int p = 0; p < P; ++p) {
-        const int shift = p * db;
-        for (int i = tid; i < W * kLdsBins; i += NT) sh.v.lhist[i] = 0;
-        __syncthreads();
-        uint32_t r[V];
+        const int sft = kshift + p * db;
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            r[v] = 0;
-            if (v < nv) {  // wave-uniform
-                const bool ok = wb + (uint32_t)(v * kWave + lane) < cnt;
-                const uint32_t d = (uint32_t)(((e[v] >> kshift) - base) >> shift) & mask;
-                const uint64_t peers = match_digit_n(d, db, ok);
-                const uint32_t rk = __popcll(peers & lt);
-                const uint32_t b0 = lh[ok ? d : 0u];
-                compiler_fence();
-                if (ok && rk == 0) lh[d] = b0 + (uint32_t)__popcll(peers);
-                compiler_fence();
-                r[v] = (d << 16) | (b0 + rk);
+        for (int i = 0; i < 8; ++i) mycw[i * NT] = 0;
+        __syncthreads();  // counters cleared, previous pass (or the staging) landed in ls
+        uint64_t e[V];
+        uint32_t r[V];
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) e[j] = mine[j];
+            uint32_t old[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const uint32_t d = (uint32_t)(e[j] >> sft) & mask;
+                r[j] = d;
+                old[j] = atomicAdd(&mycw[(d & 7u) * NT], 1u << ((d >> 3) * 16u));
             }
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[j] |= ((old[j] >> ((r[j] >> 3) * 16u)) & 0xFFu) << 8;
         }
         __syncthreads();
-        {   // offsets: exclusive scan in (digit major, wave minor) order; thread t owns digit t
-            uint32_t c[W], tot = 0;
+        {   // exclusive scan of the counters in (digit, thread) order: the words in linear order
+            // cover digits 0..7 in their low halves and 8..15 in their high halves
+            uint32_t c[8], sum = 0;
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                c[i] = sh.v.lhist[i * kLdsBins + tid];
-                tot += c[i];
+            for (int i = 0; i < 8; ++i) {
+                c[i] = cw[8 * tid + i];
+                sum += c[i];
             }
             uint32_t total;
-            uint32_t run = block_exclusive_scan<NT>(tot, sh.wsum, total);
+            uint32_t run = block_exclusive_scan<NT>(sum, sh.wsum, total);
+            run += (total & 0xFFFFu) << 16;  // every digit >= 8 comes after all digits < 8
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                sh.v.lhist[i * kLdsBins + tid] = run;
+            for (int i = 0; i < 8; ++i) {
+                cw[8 * tid + i] = run;
                 run += c[i];
             }
         }
         __syncthreads();
+        if (active) {
+            const uint64_t add = (p + 1 == P) ? bsub : 0ull;
+            uint32_t off[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            if (v < nv && wb + (uint32_t)(v * kWave + lane) < cnt) ls[lh[r[v] >> 16] + (r[v] & 0xFFFFu)] = e[v];
-        }
-        __syncthreads();
-        if (p + 1 < P) {
+            for (int j = 0; j < V; ++j) off[j] = mycw[(r[j] & 7u) * NT];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const uint32_t i = wb + (uint32_t)(v * kWave + lane);
-                if (v < nv && i < cnt) e[v] = ls[i];
+            for (int j = 0; j < V; ++j) {
+                const uint32_t d = r[j] & 15u;
+                ls[((off[j] >> ((d >> 3) * 16u)) & 0xFFFFu) + (r[j] >> 8)] = e[j] + add;
             }
         }
     }
+    __syncthreads();
 }
 
 // Writes a bucket sorted in LDS back to g[0..cnt).
