@@ -332,47 +332,38 @@ __device__ __forceinline__ void count_digits(const uint64_t* __restrict__ src, u
 // d+8 share a word and thread t's words sit at row*NT + t, so the lanes of a wave always hit
 // different banks.  The padding has the largest digit in every pass and starts out behind all
 // real elements, so stability keeps it behind them.
-template <int NT>
-__device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, uint32_t cnt, int kshift,
-                                                uint64_t base, int bits, FwdShared<NT>& sh) {
+// While in LDS an element is kept shifted left so that its sort key ends at bit 63: when the
+// key has at most 32 bits (NARROW) every digit is a bit field of the high dword.
+template <int NT, bool NARROW>
+__device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up, FwdShared<NT>& sh) {
     constexpr int V = kSortVecs;
     const int tid = threadIdx.x;
-    uint64_t* ls = sh.u.lsort;
-    if (bits <= 0) {  // all keys equal
-        for (uint32_t i = tid; i < cnt; i += NT) ls[i] = g[i];
-        __syncthreads();
-        return;
-    }
-    const uint32_t nthr = (cnt + (uint32_t)V - 1u) / (uint32_t)V;  // threads that own elements
-    const uint32_t cntp = nthr * (uint32_t)V;
     const bool active = (uint32_t)tid < nthr;
-    const uint64_t bsub = base << kshift;
-    for (uint32_t i = tid; i < cntp; i += NT) ls[i] = i < cnt ? g[i] - bsub : ~0ull;
     const int P = (bits + kLdsDigitBits - 1) / kLdsDigitBits;
     const int db = (bits + P - 1) / P;
-    const uint32_t mask = (1u << db) - 1u;
     uint32_t* cw = sh.v.cw;
     uint32_t* mycw = cw + tid;
+    uint64_t* ls = sh.u.lsort;
     const uint64_t* mine = ls + (uint32_t)tid * (uint32_t)V;
+    auto digit = [&](uint64_t y, int o) {  // o = bit offset of the digit inside the 64-bit word
+        return NARROW ? __builtin_amdgcn_ubfe((uint32_t)(y >> 32), (uint32_t)(o - 32), (uint32_t)db)
+                      : (uint32_t)(y >> o) & ((1u << db) - 1u);
+    };
     for (int p = 0; p < P; ++p) {
-        const int sft = kshift + p * db;
+        const int o = 64 - bits + p * db;
 #pragma unroll
         for (int i = 0; i < 8; ++i) mycw[i * NT] = 0;
         __syncthreads();  // counters cleared, previous pass (or the staging) landed in ls
         uint64_t e[V];
-        uint32_t r[V];
+        uint32_t old[V];
         if (active) {
 #pragma unroll
             for (int j = 0; j < V; ++j) e[j] = mine[j];
-            uint32_t old[V];
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const uint32_t d = (uint32_t)(e[j] >> sft) & mask;
-                r[j] = d;
-                old[j] = atomicAdd(&mycw[(d & 7u) * NT], 1u << ((d >> 3) * 16u));
+                const uint32_t d = digit(e[j], o);
+                old[j] = atomicAdd(&mycw[(d & 7u) * NT], 1u << ((d << 1) & 16u));
             }
-#pragma unroll
-            for (int j = 0; j < V; ++j) r[j] |= ((old[j] >> ((r[j] >> 3) * 16u)) & 0xFFu) << 8;
         }
         __syncthreads();
         {   // exclusive scan of the counters in (digit, thread) order: the words in linear order
@@ -394,24 +385,49 @@ __device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, 
         }
         __syncthreads();
         if (active) {
-            const uint64_t add = (p + 1 == P) ? bsub : 0ull;
             uint32_t off[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) off[j] = mycw[(r[j] & 7u) * NT];
+            for (int j = 0; j < V; ++j) off[j] = mycw[(digit(e[j], o) & 7u) * NT];
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const uint32_t d = r[j] & 15u;
-                ls[((off[j] >> ((d >> 3) * 16u)) & 0xFFFFu) + (r[j] >> 8)] = e[j] + add;
+                // run start and my rank inside it sit in the same half of their words
+                const uint32_t hs = (digit(e[j], o) << 1) & 16u;
+                ls[__builtin_amdgcn_ubfe(off[j] + old[j], hs, 16u)] = e[j];
             }
         }
     }
     __syncthreads();
+    (void)up;
+}
+
+template <int NT>
+__device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, uint32_t cnt, int kshift,
+                                                uint64_t base, int bits, FwdShared<NT>& sh, int& up,
+                                                uint64_t& bsub) {
+    constexpr int V = kSortVecs;
+    const int tid = threadIdx.x;
+    uint64_t* ls = sh.u.lsort;
+    up = 0;
+    bsub = 0;
+    if (bits <= 0) {  // all keys equal
+        for (uint32_t i = tid; i < cnt; i += NT) ls[i] = g[i];
+        __syncthreads();
+        return;
+    }
+    const uint32_t nthr = (cnt + (uint32_t)V - 1u) / (uint32_t)V;  // threads that own elements
+    const uint32_t cntp = nthr * (uint32_t)V;
+    up = 64 - kshift - bits;  // left shift that puts the key's top bit at bit 63
+    bsub = base << kshift;
+    for (uint32_t i = tid; i < cntp; i += NT) ls[i] = i < cnt ? (g[i] - bsub) << up : ~0ull;
+    if (bits <= 32) lds_sort_passes<NT, true>(nthr, bits, up, sh);
+    else lds_sort_passes<NT, false>(nthr, bits, up, sh);
 }
 
 // Writes a bucket sorted in LDS back to g[0..cnt).
 template <int NT>
-__device__ __forceinline__ void store_bucket(uint64_t* __restrict__ g, uint32_t cnt, FwdShared<NT>& sh) {
-    for (uint32_t i = threadIdx.x; i < cnt; i += NT) g[i] = sh.u.lsort[i];
+__device__ __forceinline__ void store_bucket(uint64_t* __restrict__ g, uint32_t cnt, int up, uint64_t bsub,
+                                             FwdShared<NT>& sh) {
+    for (uint32_t i = threadIdx.x; i < cnt; i += NT) g[i] = (sh.u.lsort[i] >> up) + bsub;
     __syncthreads();
 }
 
@@ -533,13 +549,50 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit&
             }
         }
         if (MODE == 1) {
-            // the partition needs no particular order inside a bucket, so the lane-run layout is fine
+            // The partition needs no particular order inside a bucket: every element takes its
+            // slot among the tile's elements of the same digit from an LDS counter, the tile is
+            // laid out grouped by digit in LDS and leaves in runs of consecutive slots.
+            uint32_t* tcnt = sh.u.st.tcnt[w];
+            uint32_t* tdel = sh.u.st.tdel[w];
             uint64_t* tin = sh.u.st.tin[w];
-#pragma unroll
-            for (int j = 0; j < kRun; ++j) tin[j * kWave + lane] = el[j];
+            tcnt[lane] = 0;
             compiler_fence();
-            auto valid_of = [=](int v) { return (valid_bits >> v) & 1u; };
-            scatter_staged<NT, true>(kRun, valid_of, dig, nxt, dst, r.n, has_next, ck, sh, sel, err);
+            uint32_t dj[kRun], rk[kRun];
+#pragma unroll
+            for (int j = 0; j < kRun; ++j) {
+                dj[j] = dig(el[j]);
+                rk[j] = 0;
+                if ((valid_bits >> j) & 1u) rk[j] = atomicAdd(&tcnt[dj[j]], 1u);
+            }
+            compiler_fence();
+            const uint32_t c = tcnt[lane];
+            const uint32_t incl = wave_inclusive_scan(c);
+            const uint32_t excl = incl - c;
+            const uint32_t total = __shfl(incl, kWave - 1);
+            const uint32_t g0 = c ? atomicAdd(&sh.hist[sel][lane], c) : 0u;
+            compiler_fence();
+            tcnt[lane] = excl;
+            tdel[lane] = g0 - excl;
+            compiler_fence();
+#pragma unroll
+            for (int j = 0; j < kRun; ++j)
+                if ((valid_bits >> j) & 1u) tin[tcnt[dj[j]] + rk[j]] = el[j];
+            compiler_fence();
+            uint32_t* nhist = sh.hist[sel ^ 1];
+            for (uint32_t i0 = 0; i0 < total; i0 += kWave) {
+                const uint32_t i = i0 + lane;
+                if (i < total) {
+                    const uint64_t x = tin[i];
+                    const uint32_t pos = tdel[dig(x)] + i;
+                    if (pos < r.n) {
+                        dst[pos] = x;
+                        if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + nxt(x)], 1u);
+                    } else {
+                        atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
+                    }
+                }
+            }
+            compiler_fence();
         }
     }
 }
@@ -782,7 +835,8 @@ template <int NT>
 __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t s0, uint32_t cnt,
                                               uint64_t* __restrict__ nxt, uint32_t* __restrict__ rank,
                                               uint8_t* __restrict__ out, int ibits, int kshift, int gshift,
-                                              FwdShared<NT>& sh, uint32_t& m_tot, uint32_t& g_tot) {
+                                              int up, uint64_t bsub, FwdShared<NT>& sh, uint32_t& m_tot,
+                                              uint32_t& g_tot) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
     const uint64_t* ls = sh.u.lsort;
@@ -792,14 +846,16 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
     const uint32_t hi = min(lo + ck.chunk, cnt);
     const uint64_t lt = lanemask_lt(), le = lanemask_le();
     const uint64_t imask = (1ull << ibits) - 1ull;
+    const int ks = kshift + up;  // the elements in LDS are still shifted left by `up` and lack `bsub`
     auto flags = [&](uint32_t k, uint64_t& ec, bool& head, bool& tail) {
         const bool valid = k < hi;
-        ec = valid ? ls[k] : 0ull;
-        const uint64_t key = ec >> kshift;
-        const uint64_t kp = (valid && k > 0) ? ls[k - 1] >> kshift : ~0ull;
-        const uint64_t kn = (valid && k + 1 < cnt) ? ls[k + 1] >> kshift : ~0ull;
+        const uint64_t y = valid ? ls[k] : 0ull;
+        const uint64_t key = y >> ks;
+        const uint64_t kp = (valid && k > 0) ? ls[k - 1] >> ks : ~0ull;
+        const uint64_t kn = (valid && k + 1 < cnt) ? ls[k + 1] >> ks : ~0ull;
         head = valid && kp != key;
         tail = valid && kn != key;
+        ec = (y >> up) + bsub;
         return valid;
     };
     uint32_t cA = 0, cG = 0, lH = 0;
@@ -991,9 +1047,11 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         const uint64_t base = (uint64_t)f0 << r0.fshift;
         const int bits = r0.fshift + bit_length(f1 - f0 - 1u);
         if (cnt <= (uint32_t)FwdShared<NT>::kSortCap) {
-            lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh);
-            if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, sh, m, G);
-            else store_bucket<NT>(sorted0 + s0, cnt, sh);
+            int up;
+            uint64_t bsub;
+            lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh, up, bsub);
+            if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, sh, m, G);
+            else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);
         } else {
             sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
