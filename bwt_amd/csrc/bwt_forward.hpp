@@ -61,8 +61,10 @@ constexpr size_t kBucketDirBytes = 2 * (kMaxBuckets + 1) * sizeof(uint32_t);  //
 constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition aims at (64 buckets cover 256 KiB + 1)
 
 // Per-phase time accounting (100 MHz constant clock), summed over workgroups into
-// queue[16..] as u64: 0 census, 1 round-0 digit count, 2 round-0 sort, 3 round-0 rerank,
-// 4 later key builds, 5 later sorts, 6 later reranks, 7 full-rank rebuilds, 8 blocks, 9 later rounds.
+// queue[16..] as u64: 0 census, 1 round-0 fine-bin count, 2 round-0 partition, 3 round-0 rerank
+// sweep (when not fused), 4 later key builds, 5 later sorts, 6 later reranks, 7 full-rank
+// rebuilds, 8 blocks, 9 later rounds, 10 round-0 rerank of buckets in LDS (or their plain
+// write-back), 11 round-0 bucket sorts through HBM, 12 round-0 bucket sorts in LDS.
 struct PhaseClock {
     unsigned long long t;
     unsigned long long* acc;
@@ -1050,6 +1052,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             int up;
             uint64_t bsub;
             lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh, up, bsub);
+            pc.lap(12);
             if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, sh, m, G);
             else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);

@@ -17,12 +17,16 @@
 // The walk itself is a pointer chase of n dependent loads; one chain per block leaves the
 // memory system idle, so a well-formed block (exactly one delimiter) is cut into segments:
 // every kSplitStride-th row and the delimiter row are "splitters"; one lane per splitter
-// walks until it reaches the next splitter (whose own byte it still emits), writing its bytes
-// into 256-byte chunks drawn
-// from a per-block pool (bwt_inverse_walk_segments_kernel).  A stitch pass orders the
-// segments by following next-splitter links from the delimiter row
-// (bwt_inverse_stitch_kernel) and a copy pass reverses every chunk into its final place
-// (bwt_inverse_place_kernel).  The result is the chain the reference walks, byte for byte.
+// walks until it reaches the next splitter (whose own byte still belongs to it).
+//   bwt_inverse_walk_count_kernel   every segment's length and the splitter it runs into
+//   bwt_inverse_stitch_kernel       orders the segments by following those links from the
+//                                   delimiter row: where each segment's bytes go
+//   bwt_inverse_walk_write_kernel   walks every segment again and writes its bytes in place
+// Walking twice is cheaper than walking once through HBM: the lanes of a block are placed on
+// ONE XCD (workgroup w runs on XCD w % 8), and with a splitter every 32 rows a block brings
+// enough lanes that an XCD works on only a few blocks at a time, whose LF tables (4 bytes per
+// row) then stay in that XCD's 4 MiB L2: a dependent random load costs an L2 hit instead of a
+// 64-byte HBM transaction.  The result is the chain the reference walks, byte for byte.
 // Blocks with several delimiters (only possible for hand-made input) keep the reference's
 // exact semantics -- start at the last delimiter row, stop at the first delimiter reached --
 // through the single-chain kernel (bwt_inverse_walk_kernel), as do blocks too short to split.
@@ -34,8 +38,9 @@ namespace bwtgpu {
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr uint32_t kRowMask = 0x007FFFFFu;   // successor row (n <= 2^21 < 2^23)
 constexpr uint32_t kSplitFlag = 0x00800000u; // this row starts a segment
-constexpr uint32_t kSplitStride = 1024;      // rows between regular splitters
-constexpr uint32_t kChunk = 256;             // bytes per pool chunk
+constexpr uint32_t kSplitStride = 32;        // rows between regular splitters
+constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain
+constexpr int kSegThreads = 256;             // workgroup size of the segment kernels
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 constexpr uint32_t kModeMulti = 0, kModeSingle = 1, kModeNone = 2;
 
@@ -48,16 +53,12 @@ struct InvArgs {
     uint32_t delim;
     uint32_t tstride;     // LF-table words per block (>= block_size+1)
     uint32_t seg_cap;     // segment slots per block (regular splitters + 1)
-    uint32_t chunk_cap;   // pool chunks per block
+    uint32_t seg_wgs;     // workgroups of kSegThreads lanes that cover one block's segments
     uint32_t* T;          // nblocks * tstride words
     uint32_t* drow;       // per block: delimiter row or kNoRow
     uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
-    uint32_t* pool_used;  // per block: chunks handed out
-    uint32_t* seg_len;    // nblocks * seg_cap: bytes a segment produced
-    uint32_t* seg_next;   // nblocks * seg_cap: id of the splitter the segment ran into
+    uint2* seg;           // nblocks * seg_cap: x = bytes the segment produces, y = id of the splitter it runs into
     uint32_t* seg_pos;    // nblocks * seg_cap: bytes between the segment's first byte and the text end
-    uint32_t* chunk_meta; // nblocks * chunk_cap: owner segment << 16 | ordinal within the segment
-    uint8_t* pool;        // nblocks * chunk_cap * kChunk bytes
     uint32_t* lens;       // per block: text length or BWTGPU_LEN_NO_DELIMITER
     uint32_t* queue;      // [0] next block index to hand out
 };
@@ -139,11 +140,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
             if (sh.drow[i] != kNoRow) drow = sh.drow[i];
         // split the walk only when it is the plain single-delimiter case and long enough to pay
         const uint32_t mode = drow == kNoRow ? kModeNone
-                              : (sh.ndelim == 1u && n >= 4u * kSplitStride) ? kModeMulti : kModeSingle;
+                              : (sh.ndelim == 1u && n >= kMultiMinRows) ? kModeMulti : kModeSingle;
         if (tid == 0) {
             a.drow[b] = drow;
             a.mode[b] = mode;
-            a.pool_used[b] = 0;
         }
         const bool split = mode == kModeMulti;
         // pass 2: LF table
@@ -234,70 +234,48 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
 }
 
 // ---- segmented walk -------------------------------------------------------------------------
-// Lane (b, j): segment j of block b.  j < regular_splitters(n) starts at row j * stride,
-// j == regular_splitters(n) starts at the delimiter row.  (A regular splitter that IS the
-// delimiter row is left to the latter.)
-__global__ __launch_bounds__(kWave) void bwt_inverse_walk_segments_kernel(InvArgs a) {
-    const uint64_t gid = (uint64_t)blockIdx.x * kWave + threadIdx.x;
-    const uint32_t b = (uint32_t)(gid / a.seg_cap);
-    const uint32_t j = (uint32_t)(gid % a.seg_cap);
-    if (b >= a.nblocks || a.mode[b] != kModeMulti) return;
+// Lane -> (block, segment).  Workgroups are dealt to the XCDs round robin, so workgroup w of
+// the grid serves block (w / 8 / seg_wgs) * 8 + w % 8: all workgroups of one block share an
+// XCD, and an XCD works through its blocks in order.  (If the hardware placed workgroups
+// differently only the cache locality would suffer.)
+// Segment j < regular_splitters(n) starts at row j * stride, j == regular_splitters(n) starts
+// at the delimiter row.  (A regular splitter that IS the delimiter row is left to the latter.)
+__device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, uint32_t& j) {
+    const uint32_t w = blockIdx.x, x = w & 7u, q = w >> 3;
+    b = (q / a.seg_wgs) * 8u + x;
+    j = (q % a.seg_wgs) * (uint32_t)kSegThreads + threadIdx.x;
+    return b < a.nblocks && a.mode[b] == kModeMulti;
+}
+
+__global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_count_kernel(InvArgs a) {
+    uint32_t b, j;
+    if (!segment_of_lane(a, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
     const uint32_t nreg = regular_splitters(n);
     if (j > nreg) return;
     const uint32_t drow = a.drow[b];
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     a.seg_pos[sb + j] = kNoPos;
-    a.seg_len[sb + j] = 0;
-    a.seg_next[sb + j] = j;
     const uint32_t start = j < nreg ? j * kSplitStride : drow;
-    if (j < nreg && start == drow) return;
+    if (j < nreg && start == drow) {
+        a.seg[sb + j] = make_uint2(0u, j);
+        return;
+    }
     const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
-    uint8_t* const pool = a.pool + (uint64_t)b * a.chunk_cap * kChunk;
-    uint32_t* const meta = a.chunk_meta + (uint64_t)b * a.chunk_cap;
     uint32_t row = T[start] & kRowMask;
-    uint32_t t = 0;  // bytes produced
-    uint32_t acc = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    uint8_t* chunk = nullptr;
+    uint32_t t = 0;  // bytes the segment produces
     uint32_t stop = start;
     for (uint32_t step = 0; step < n; ++step) {
         const uint32_t wd = T[row];
-        const bool at_splitter = (wd & kSplitFlag) != 0u;
-        if (at_splitter && row == drow) {  // back at the delimiter row: the text ends here
+        if (wd & kSplitFlag) {
             stop = row;
-            break;
+            if (row != drow) ++t;  // a splitter's own byte belongs to the segment that reaches it;
+            break;                 // the delimiter row ends the text and has no byte
         }
-        if ((t & (kChunk - 1u)) == 0u) {  // need a fresh chunk
-            const uint32_t c = atomicAdd(&a.pool_used[b], 1u);
-            if (c >= a.chunk_cap) break;  // cannot happen: the pool holds n/kChunk + segments chunks
-            meta[c] = (j << 16) | (t / kChunk);
-            chunk = pool + (uint64_t)c * kChunk;
-        }
-        acc |= (wd >> 24) << (8u * (t & 3u));
         ++t;
-        if ((t & 3u) == 0u) {
-            q0 = q1; q1 = q2; q2 = q3; q3 = acc;
-            acc = 0;
-            if ((t & 15u) == 0u)
-                *reinterpret_cast<uint4*>(chunk + ((t - 16u) & (kChunk - 1u))) = make_uint4(q0, q1, q2, q3);
-        }
-        if (at_splitter) {  // this row's byte belongs to this segment; the next segment starts after it
-            stop = row;
-            break;
-        }
         row = wd & kRowMask;
     }
-    if (t & 15u) {  // flush the partial 16-byte group (the chunk has room; bytes past t are never read)
-        const uint32_t have = (t & 15u) >> 2;  // complete dwords in the group: q3 newest
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-        if (have == 0) { d0 = acc; }
-        else if (have == 1) { d0 = q3; d1 = acc; }
-        else if (have == 2) { d0 = q2; d1 = q3; d2 = acc; }
-        else { d0 = q1; d1 = q2; d2 = q3; d3 = acc; }
-        *reinterpret_cast<uint4*>(chunk + ((t & ~15u) & (kChunk - 1u))) = make_uint4(d0, d1, d2, d3);
-    }
-    a.seg_len[sb + j] = t;
-    a.seg_next[sb + j] = stop == drow ? nreg : stop / kSplitStride;
+    a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : stop / kSplitStride);
 }
 
 // Orders the segments of every split block: start at the delimiter row's segment, follow the
@@ -311,41 +289,87 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_stitch_kernel(InvArgs a) {
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     uint32_t id = nreg, total = 0;
     for (uint32_t it = 0; it <= nreg; ++it) {
+        const uint2 sg = a.seg[sb + id];
         a.seg_pos[sb + id] = total;
-        total += a.seg_len[sb + id];
-        const uint32_t nx = a.seg_next[sb + id];
-        if (nx >= nreg) break;  // back at the delimiter row: the text is complete
-        id = nx;
+        total += sg.x;
+        if (sg.y >= nreg) break;  // back at the delimiter row: the text is complete
+        id = sg.y;
     }
     a.lens[b] = total < n ? total : n - 1;
 }
 
-// Moves every chunk of a chained segment to its place, reversed.  One workgroup per block.
-template <int NT>
-__global__ __launch_bounds__(NT) void bwt_inverse_place_kernel(InvArgs a) {
-    const uint32_t b = blockIdx.x;
-    if (a.mode[b] != kModeMulti) return;
-    const uint32_t n = inv_block_len(a, b);
-    const uint32_t used = min(a.pool_used[b], a.chunk_cap);
-    const uint64_t sb = (uint64_t)b * a.seg_cap;
-    const uint8_t* const pool = a.pool + (uint64_t)b * a.chunk_cap * kChunk;
-    const uint32_t* const meta = a.chunk_meta + (uint64_t)b * a.chunk_cap;
-    uint8_t* const text_end = a.out + (uint64_t)b * a.block_size + (n - 1);
-    const int lane = lane_id();
-    for (uint32_t c = wave_id(); c < used; c += NT / kWave) {
-        const uint32_t mt = meta[c];
-        const uint32_t seg = mt >> 16, ord = mt & 0xFFFFu;
-        const uint32_t pos = a.seg_pos[sb + seg];
-        if (pos == kNoPos) continue;  // a segment on a cycle the delimiter's chain never reaches
-        const uint32_t slen = a.seg_len[sb + seg];
-        const uint32_t off = ord * kChunk;
-        if (off >= slen) continue;
-        const uint32_t cnt = min(kChunk, slen - off);
-        const uint8_t* src = pool + (uint64_t)c * kChunk;
-        const uint64_t back = (uint64_t)pos + off;  // bytes between text_end and this chunk's first byte
-        if (back + cnt > (uint64_t)(n - 1)) continue;  // never: the chain is at most n-1 bytes long
-        for (uint32_t u = lane; u < cnt; u += kWave) text_end[-(int64_t)(back + u) - 1] = src[u];
+// Collects bytes that arrive back to front and stores them below `end`: whole aligned 16-byte
+// groups where possible, single dwords and bytes at the two ragged ends, never a byte outside
+// [end - count, end).
+struct BackWriter {
+    uint8_t* addr;   // lowest address produced so far
+    uint8_t* daddr;  // where the completed dwords q0.. start
+    uint32_t acc, cnt, q0, q1, q2, q3, dcnt;
+    __device__ __forceinline__ void init(uint8_t* end) {
+        addr = daddr = end;
+        acc = cnt = q0 = q1 = q2 = q3 = dcnt = 0;
     }
+    __device__ __forceinline__ void push(uint32_t ch) {
+        acc = (acc << 8) | ch;
+        ++cnt;
+        --addr;
+        if ((reinterpret_cast<uintptr_t>(addr) & 3u) == 0) {
+            if (cnt == 4) {
+                q3 = q2; q2 = q1; q1 = q0; q0 = acc;
+                daddr = addr;
+                ++dcnt;
+                if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
+                    if (dcnt == 4) {
+                        *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
+                    } else {
+                        uint32_t* d = reinterpret_cast<uint32_t*>(addr);
+                        d[0] = q0;
+                        if (dcnt > 1) d[1] = q1;
+                        if (dcnt > 2) d[2] = q2;
+                    }
+                    dcnt = 0;
+                }
+            } else {  // ragged upper end: the first dword is partial
+                for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
+            }
+            acc = 0;
+            cnt = 0;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
+        if (dcnt) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(daddr);
+            d[0] = q0;
+            if (dcnt > 1) d[1] = q1;
+            if (dcnt > 2) d[2] = q2;
+            if (dcnt > 3) d[3] = q3;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_write_kernel(InvArgs a) {
+    uint32_t b, j;
+    if (!segment_of_lane(a, b, j)) return;
+    const uint32_t n = inv_block_len(a, b);
+    const uint32_t nreg = regular_splitters(n);
+    if (j > nreg) return;
+    const uint64_t sb = (uint64_t)b * a.seg_cap;
+    const uint32_t pos = a.seg_pos[sb + j];
+    if (pos == kNoPos) return;  // a segment on a cycle the delimiter's chain never reaches
+    const uint32_t len = a.seg[sb + j].x;
+    if ((uint64_t)pos + len > (uint64_t)(n - 1)) return;  // never: the chain is at most n-1 bytes long
+    const uint32_t start = j < nreg ? j * kSplitStride : a.drow[b];
+    const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    BackWriter bw;
+    bw.init(a.out + (uint64_t)b * a.block_size + (n - 1) - pos);
+    uint32_t row = T[start] & kRowMask;
+    for (uint32_t step = 0; step < len; ++step) {
+        const uint32_t wd = T[row];
+        bw.push(wd >> 24);
+        row = wd & kRowMask;
+    }
+    bw.flush();
 }
 
 }  // namespace bwtgpu

@@ -109,9 +109,9 @@ struct InvGeom {
     size_t nblocks;
     uint32_t tstride;
     uint32_t build_grid;
-    uint32_t seg_cap, chunk_cap;
+    uint32_t seg_cap, seg_wgs;
     bool split;  // blocks are long enough for the segmented walk
-    size_t drow_off, mode_off, used_off, seglen_off, segnext_off, segpos_off, meta_off, t_off, pool_off, bytes;
+    size_t drow_off, mode_off, seg_off, segpos_off, t_off, bytes;
 };
 
 InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
@@ -122,9 +122,9 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.tstride = (uint32_t)round_up(longest, 64);
     const size_t max_wgs = (size_t)d.cus * (size_t)d.inv_wgs_per_cu;
     g.build_grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
-    g.split = longest >= 4u * kSplitStride;
+    g.split = longest >= kMultiMinRows;
     g.seg_cap = g.split ? regular_splitters((uint32_t)longest) + 1u : 1u;
-    g.chunk_cap = g.split ? (uint32_t)(longest / kChunk) + g.seg_cap + 8u : 1u;
+    g.seg_wgs = (g.seg_cap + kSegThreads - 1) / kSegThreads;
     size_t off = kHeaderBytes;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -133,13 +133,9 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     };
     g.drow_off = take(g.nblocks * 4);
     g.mode_off = take(g.nblocks * 4);
-    g.used_off = take(g.nblocks * 4);
-    g.seglen_off = take(g.nblocks * g.seg_cap * 4);
-    g.segnext_off = take(g.nblocks * g.seg_cap * 4);
+    g.seg_off = take(g.nblocks * g.seg_cap * 8);
     g.segpos_off = take(g.nblocks * g.seg_cap * 4);
-    g.meta_off = take(g.nblocks * (size_t)g.chunk_cap * 4);
     g.t_off = take((size_t)g.tstride * 4 * g.nblocks);
-    g.pool_off = take(g.nblocks * (size_t)g.chunk_cap * kChunk);
     g.bytes = off;
     return g;
 }
@@ -437,16 +433,12 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.delim = delimiter;
     a.tstride = g.tstride;
     a.seg_cap = g.seg_cap;
-    a.chunk_cap = g.chunk_cap;
+    a.seg_wgs = g.seg_wgs;
     a.T = (uint32_t*)(ws + g.t_off);
     a.drow = (uint32_t*)(ws + g.drow_off);
     a.mode = (uint32_t*)(ws + g.mode_off);
-    a.pool_used = (uint32_t*)(ws + g.used_off);
-    a.seg_len = (uint32_t*)(ws + g.seglen_off);
-    a.seg_next = (uint32_t*)(ws + g.segnext_off);
+    a.seg = (uint2*)(ws + g.seg_off);
     a.seg_pos = (uint32_t*)(ws + g.segpos_off);
-    a.chunk_meta = (uint32_t*)(ws + g.meta_off);
-    a.pool = ws + g.pool_off;
     a.lens = d_out_lens;
     a.queue = (uint32_t*)d_workspace;
     hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
@@ -455,14 +447,13 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     hipLaunchKernelGGL(bwt_inverse_walk_kernel, dim3(per_block_grid), dim3(kWave), 0, s, a);
     HIP_TRY(hipGetLastError());
     if (g.split) {
-        const uint64_t lanes = (uint64_t)g.nblocks * g.seg_cap;
-        if ((lanes + kWave - 1) / kWave > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
-        hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel, dim3((uint32_t)((lanes + kWave - 1) / kWave)), dim3(kWave),
-                           0, s, a);
+        const uint64_t wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * g.seg_wgs;
+        if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
+        hipLaunchKernelGGL(bwt_inverse_walk_count_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bwt_inverse_stitch_kernel, dim3(per_block_grid), dim3(kWave), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bwt_inverse_place_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(bwt_inverse_walk_write_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     return BWTGPU_OK;
