@@ -32,6 +32,7 @@
 // through the single-chain kernel (bwt_inverse_walk_kernel), as do blocks too short to split.
 #pragma once
 #include "bwt_device.hpp"
+#include "bwtgpu.h"
 
 namespace bwtgpu {
 
@@ -281,21 +282,66 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_count_kernel(Inv
 // Orders the segments of every split block: start at the delimiter row's segment, follow the
 // next-splitter links until the chain returns to it.  seg_pos = bytes before the segment,
 // counted from the END of the text (the walk produces the text back to front).
-__global__ __launch_bounds__(kWave) void bwt_inverse_stitch_kernel(InvArgs a) {
-    const uint32_t b = blockIdx.x * kWave + threadIdx.x;
-    if (b >= a.nblocks || a.mode[b] != kModeMulti) return;
+// One workgroup per block.  Following thousands of links one after the other would take
+// milliseconds, so every kSuperStride-th segment (and the delimiter's) is a "super" node:
+// each thread follows the links from its super node to the next one, summing the lengths
+// (short independent chains), one thread then orders the few hundred super nodes, and each
+// thread walks its chain again to hand out the positions.
+constexpr uint32_t kSuperStride = 32;
+constexpr uint32_t kMaxSupers = (BWTGPU_MAX_BLOCK_SIZE + 1u) / kSplitStride / kSuperStride + 2u;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
+    __shared__ uint32_t s_sum[kMaxSupers], s_next[kMaxSupers], s_pos[kMaxSupers];
+    const uint32_t b = blockIdx.x;
+    if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
     const uint32_t nreg = regular_splitters(n);
     const uint64_t sb = (uint64_t)b * a.seg_cap;
-    uint32_t id = nreg, total = 0;
-    for (uint32_t it = 0; it <= nreg; ++it) {
-        const uint2 sg = a.seg[sb + id];
-        a.seg_pos[sb + id] = total;
-        total += sg.x;
-        if (sg.y >= nreg) break;  // back at the delimiter row: the text is complete
-        id = sg.y;
+    const uint32_t last = (nreg + kSuperStride - 1u) / kSuperStride;  // super index of the delimiter's segment
+    auto super_of = [&](uint32_t id) {  // super index of segment id, or kNoPos
+        if (id >= nreg) return last;
+        return (id % kSuperStride) == 0u ? id / kSuperStride : kNoPos;
+    };
+    for (uint32_t u = threadIdx.x; u <= last; u += NT) {
+        uint32_t id = u == last ? nreg : u * kSuperStride;
+        uint32_t sum = 0, nx = kNoPos;
+        for (uint32_t it = 0; it <= nreg; ++it) {  // bounded: a malformed block may link segments in a cycle
+            const uint2 sg = a.seg[sb + id];
+            sum += sg.x;
+            nx = super_of(sg.y);
+            if (nx != kNoPos) break;
+            id = sg.y;
+        }
+        s_sum[u] = sum;
+        s_next[u] = nx;
+        s_pos[u] = kNoPos;
     }
-    a.lens[b] = total < n ? total : n - 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t cur = last, total = 0;
+        for (uint32_t it = 0; it <= last; ++it) {
+            s_pos[cur] = total;
+            total += s_sum[cur];
+            const uint32_t nx = s_next[cur];
+            if (nx == last || nx == kNoPos) break;  // back at the delimiter row: the text is complete
+            cur = nx;
+        }
+        a.lens[b] = total < n ? total : n - 1;
+    }
+    __syncthreads();
+    for (uint32_t u = threadIdx.x; u <= last; u += NT) {
+        uint32_t pos = s_pos[u];
+        if (pos == kNoPos) continue;  // a chain the delimiter's chain never reaches
+        uint32_t id = u == last ? nreg : u * kSuperStride;
+        for (uint32_t it = 0; it <= nreg; ++it) {
+            const uint2 sg = a.seg[sb + id];
+            a.seg_pos[sb + id] = pos;
+            pos += sg.x;
+            if (super_of(sg.y) != kNoPos) break;
+            id = sg.y;
+        }
+    }
 }
 
 // Collects bytes that arrive back to front and stores them below `end`: whole aligned 16-byte

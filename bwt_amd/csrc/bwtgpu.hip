@@ -451,7 +451,7 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
         hipLaunchKernelGGL(bwt_inverse_walk_count_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bwt_inverse_stitch_kernel, dim3(per_block_grid), dim3(kWave), 0, s, a);
+        hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bwt_inverse_walk_write_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
