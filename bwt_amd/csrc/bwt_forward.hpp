@@ -832,7 +832,9 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
 // writes the bucket back to g, stores the output byte of every suffix that is alone in its run,
 // and for the others writes rank (= global position of the run's first element) and appends
 // (dense group id << gshift | index) to nxt.  m_tot / g_tot are the running survivor and group
-// counts of the block and are advanced.
+// counts of the block and are advanced.  The elements in LDS are still shifted left by `up`
+// and lack `bsub` (see lds_sort_bucket).  A first sweep finds the run heads and tails of every
+// 64-element vector (kept as ballots in v.cw) and counts; the second one acts on them.
 template <int NT>
 __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t s0, uint32_t cnt,
                                               uint64_t* __restrict__ nxt, uint32_t* __restrict__ rank,
@@ -848,27 +850,52 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
     const uint32_t hi = min(lo + ck.chunk, cnt);
     const uint64_t lt = lanemask_lt(), le = lanemask_le();
     const uint64_t imask = (1ull << ibits) - 1ull;
-    const int ks = kshift + up;  // the elements in LDS are still shifted left by `up` and lack `bsub`
-    auto flags = [&](uint32_t k, uint64_t& ec, bool& head, bool& tail) {
-        const bool valid = k < hi;
-        const uint64_t y = valid ? ls[k] : 0ull;
-        const uint64_t key = y >> ks;
-        const uint64_t kp = (valid && k > 0) ? ls[k - 1] >> ks : ~0ull;
-        const uint64_t kn = (valid && k + 1 < cnt) ? ls[k + 1] >> ks : ~0ull;
-        head = valid && kp != key;
-        tail = valid && kn != key;
-        ec = (y >> up) + bsub;
-        return valid;
-    };
+    const int ks = kshift + up;
+    constexpr int kVecsPerWave = FwdShared<NT>::kSortCap / NT + 5;  // a wave's chunk is at most 20 vectors; reads run up to 3 past it
+    uint64_t* flags = reinterpret_cast<uint64_t*>(sh.v.cw) + (size_t)w * 2 * kVecsPerWave;
+    static_assert(sizeof(sh.v.cw) >= (size_t)W * 2 * kVecsPerWave * sizeof(uint64_t), "room for two ballots per vector");
     uint32_t cA = 0, cG = 0, lH = 0;
-    for (uint32_t base = lo; base < hi; base += kWave) {
-        uint64_t ec;
-        bool head, tail;
-        const bool valid = flags(base + lane, ec, head, tail);
-        const uint64_t H = __ballot(head);
-        cA += __popcll(__ballot(valid && !(head && tail)));
-        cG += __popcll(__ballot(head && !tail));
-        if (H) lH = base + 63u - (uint32_t)__clzll(H);
+    constexpr int U = 4;  // vectors whose LDS reads are issued together (the loop is latency bound otherwise)
+    const uint32_t kmax = cnt - 1u;
+    {
+        uint32_t v = 0;
+        for (uint32_t base = lo; base < hi; base += U * kWave, v += U) {
+            uint64_t key[U], kp[U], kn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // clamped indices: every read is in range, the flags below sort out validity
+                const uint32_t k = base + (uint32_t)(u * kWave + lane);
+                const uint32_t kc = min(k, kmax), kl = min(k - 1u, kmax), kr = min(k + 1u, kmax);
+                if (ks >= 32) {  // the key fits the high dword: 4-byte LDS reads
+                    const uint32_t* hi32 = reinterpret_cast<const uint32_t*>(ls) + 1;
+                    const int sh32 = ks - 32;
+                    key[u] = hi32[2 * kc] >> sh32;
+                    kp[u] = hi32[2 * kl] >> sh32;
+                    kn[u] = hi32[2 * kr] >> sh32;
+                } else {
+                    key[u] = ls[kc] >> ks;
+                    kp[u] = ls[kl] >> ks;
+                    kn[u] = ls[kr] >> ks;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t vb = base + (uint32_t)(u * kWave);
+                if (vb < hi) {  // wave-uniform
+                    const uint32_t k = vb + lane;
+                    const bool valid = k < hi;
+                    const bool head = valid && (k == 0 || kp[u] != key[u]);
+                    const bool tail = valid && (k + 1 == cnt || kn[u] != key[u]);
+                    const uint64_t H = __ballot(head), T = __ballot(tail);
+                    if (lane == 0) {
+                        flags[2 * (v + u)] = H;
+                        flags[2 * (v + u) + 1] = T;
+                    }
+                    cA += __popcll(__ballot(valid) & ~(H & T));
+                    cG += __popcll(H & ~T);
+                    if (H) lH = vb + 63u - (uint32_t)__clzll(H);
+                }
+            }
+        }
     }
     if (lane == 0) {
         sh.cntA[w] = cA;
@@ -888,32 +915,49 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
         totA += ca;
         totG += cg;
     }
-    for (uint32_t base = lo; base < hi; base += kWave) {
-        uint64_t ec;
-        bool head, tail;
-        const bool valid = flags(base + lane, ec, head, tail);
-        const uint64_t H = __ballot(head);
-        const uint64_t hm = H & le;
-        const uint32_t khead = hm ? base + 63u - (uint32_t)__clzll(hm) : carryH;
-        if (H) carryH = base + 63u - (uint32_t)__clzll(H);
-        const bool single = head && tail;
-        const bool act = valid && !single;
-        const uint64_t A = __ballot(act), NS = __ballot(head && !tail);
-        const uint32_t idx = (uint32_t)(ec & imask);
-        if (valid) g[base + lane] = ec;
-        if (single) out[s0 + base + lane] = (uint8_t)(ec >> ibits);
-        if (act) {
-            rank[idx] = s0 + khead;
-            const uint32_t pos = baseA + __popcll(A & lt);
-            const uint32_t gid = baseG + __popcll(NS & le) - 1u;
-            nxt[pos] = ((uint64_t)gid << gshift) | idx;
+    {
+        uint32_t v = 0;
+        for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave, v += U) {
+            uint64_t y[U], Hs[U], Ts[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                y[u] = ls[min(base0 + (uint32_t)(u * kWave + lane), kmax)];
+                Hs[u] = flags[2 * (v + u)];
+                Ts[u] = flags[2 * (v + u) + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t base = base0 + (uint32_t)(u * kWave);
+                if (base < hi) {  // wave-uniform
+                    const uint32_t k = base + lane;
+                    const bool valid = k < hi;
+                    const uint64_t H = Hs[u], T = Ts[u];
+                    const uint64_t ec = (y[u] >> up) + bsub;
+                    const uint64_t hm = H & le;
+                    const uint32_t khead = hm ? base + 63u - (uint32_t)__clzll(hm) : carryH;
+                    if (H) carryH = base + 63u - (uint32_t)__clzll(H);
+                    const bool head = (H >> lane) & 1u, tail = (T >> lane) & 1u;
+                    const bool single = head && tail;
+                    const bool act = valid && !single;
+                    const uint64_t A = __ballot(valid) & ~(H & T), NS = H & ~T;
+                    const uint32_t idx = (uint32_t)(ec & imask);
+                    if (valid) g[k] = ec;
+                    if (single) out[s0 + k] = (uint8_t)(ec >> ibits);
+                    if (act) {
+                        rank[idx] = s0 + khead;
+                        const uint32_t pos = baseA + __popcll(A & lt);
+                        const uint32_t gid = baseG + __popcll(NS & le) - 1u;
+                        nxt[pos] = ((uint64_t)gid << gshift) | idx;
+                    }
+                    baseA += __popcll(A);
+                    baseG += __popcll(NS);
+                }
+            }
         }
-        baseA += __popcll(A);
-        baseG += __popcll(NS);
     }
     m_tot += totA;
     g_tot += totG;
-    __syncthreads();  // cntA/cntG/lastH and the LDS bucket are free again
+    __syncthreads();  // cntA/cntG/lastH, the ballots and the LDS bucket are free again
 }
 
 // Rank of suffix j by its first m0 symbols = number of round-0 elements with a smaller key:
@@ -992,7 +1036,13 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     r0.kmask = (1ull << kbits) - 1ull;
     const int kshift0 = ibits + 8;
     BucketDigit dig{sh.v.lut, kshift0 + r0.fshift, 0, 0u}, dig2 = dig;
-    round0_sweep<NT, 0>(r0, dig, dig2, false, nullptr, sh, 0, &queue[1]);
+    {   // the fine bin only needs the first few symbols of the key: a shorter window
+        Round0 rc = r0;
+        rc.m0 = min(m0, (fbits + sbits - 1) / sbits);
+        rc.kmask = (1ull << (rc.m0 * sbits)) - 1ull;
+        rc.fshift = rc.m0 * sbits - fbits;
+        round0_sweep<NT, 0>(rc, dig, dig2, false, nullptr, sh, 0, &queue[1]);
+    }
     __syncthreads();
     pc.lap(1);
     BucketDir dir;
