@@ -159,3 +159,35 @@ def test_benchmark_shapes_against_oracle(orc, kind, bs):
     got = api.forward_batch(data, bs, delim)
     assert got == want[1:]
     assert api.inverse_batch(got, bs, delim) == data
+
+
+def test_skewed_distributions_and_many_blocks(orc):
+    """Inputs that stress the round-0 bucket partition (one dominant key range that does not fit an
+    LDS bucket, sparse key space, runs of equal bytes) and a batch whose block count is not a
+    multiple of 8 (the inverse spreads blocks over the 8 XCDs)."""
+    rng = np.random.default_rng(77)
+    cases = []
+    # 90 % one byte, rest uniform over 200 values: most suffixes share their first symbols
+    a = rng.integers(0, 200, size=300000, dtype=np.uint8)
+    a[rng.random(300000) < 0.9] = 65
+    cases.append((a.tobytes(), 131072))
+    # long runs of equal bytes separated by random text
+    b = np.concatenate([np.full(30000, 7, np.uint8), rng.integers(0, 250, size=50000, dtype=np.uint8),
+                        np.full(70000, 9, np.uint8), rng.integers(30, 40, size=60000, dtype=np.uint8)])
+    cases.append((b.tobytes(), 262144))
+    # two symbols only, block of 1 MiB: 17-symbol keys, two partition passes
+    c = rng.integers(0, 2, size=1048576 + 999, dtype=np.uint8) + 100
+    cases.append((c.tobytes(), 1048576))
+    # 37 blocks of 8 KiB + ragged tail
+    d = rng.integers(0, 255, size=37 * 8192 + 123, dtype=np.uint8)
+    cases.append((d.tobytes(), 8192))
+    # text-like: words from a small vocabulary
+    vocab = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(50)]
+    e = b" ".join(vocab[int(i)] for i in rng.integers(0, 50, size=60000))
+    cases.append((e, 262144))
+    for data, bs in cases:
+        want = orc.forward_buffer(data, bs, 8)
+        delim = want[0]
+        got = api.forward_batch(data, bs, delim)
+        assert got == want[1:], (len(data), bs)
+        assert api.inverse_batch(got, bs, delim) == data, (len(data), bs)
