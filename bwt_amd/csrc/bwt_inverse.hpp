@@ -109,13 +109,22 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, n);
         // pass 1: histogram per wave chunk + last delimiter row
         uint32_t last = kNoRow;
-        for (uint32_t base = lo; base < hi; base += kWave) {
-            const uint32_t k = base + lane;
-            const bool valid = k < hi;
-            const uint32_t c = valid ? L[k] : 0u;
-            if (valid) atomicAdd(&sh.hist[w * 256 + c], 1u);
-            const uint64_t isd = __ballot(valid && c == a.delim);
-            if (isd) last = base + 63u - (uint32_t)__clzll(isd);
+        constexpr int U = 4;  // vectors whose loads are issued together
+        for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+            uint32_t cs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cs[u] = L[min(base0 + (uint32_t)(u * kWave + lane), n - 1u)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t base = base0 + (uint32_t)(u * kWave);
+                if (base < hi) {  // wave-uniform
+                    const bool valid = base + lane < hi;
+                    const uint32_t c = cs[u];
+                    if (valid) atomicAdd(&sh.hist[w * 256 + c], 1u);
+                    const uint64_t isd = __ballot(valid && c == a.delim);
+                    if (isd) last = base + 63u - (uint32_t)__clzll(isd);
+                }
+            }
         }
         if (lane == 0) sh.drow[w] = last;
         __syncthreads();
@@ -149,18 +158,27 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         const bool split = mode == kModeMulti;
         // pass 2: LF table
         uint32_t* myoff = sh.hist + w * 256;
-        for (uint32_t base = lo; base < hi; base += kWave) {
-            const uint32_t k = base + lane;
-            const bool valid = k < hi;
-            const uint32_t c = valid ? L[k] : 0u;
-            const uint64_t peers = match_digit<8>(c, valid);
-            const uint32_t rk = __popcll(peers & lt);
-            const uint32_t b0 = myoff[c];
-            compiler_fence();  // every lane has read its offset before the leaders advance it
-            if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
-            compiler_fence();
-            const uint32_t flag = (split && ((k & (kSplitStride - 1u)) == 0u || k == drow)) ? kSplitFlag : 0u;
-            if (valid) T[k] = (b0 + rk) | flag | (c << 24);
+        for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+            uint32_t cs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cs[u] = L[min(base0 + (uint32_t)(u * kWave + lane), n - 1u)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t base = base0 + (uint32_t)(u * kWave);
+                if (base < hi) {  // wave-uniform
+                    const uint32_t k = base + lane;
+                    const bool valid = k < hi;
+                    const uint32_t c = cs[u];
+                    const uint64_t peers = match_digit<8>(c, valid);
+                    const uint32_t rk = __popcll(peers & lt);
+                    const uint32_t b0 = myoff[c];
+                    compiler_fence();  // every lane has read its offset before the leaders advance it
+                    if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
+                    compiler_fence();
+                    const uint32_t flag = (split && ((k & (kSplitStride - 1u)) == 0u || k == drow)) ? kSplitFlag : 0u;
+                    if (valid) T[k] = (b0 + rk) | flag | (c << 24);
+                }
+            }
         }
         __syncthreads();
     }

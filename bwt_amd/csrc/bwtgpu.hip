@@ -449,11 +449,13 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     if (g.split) {
         const uint64_t wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * g.seg_wgs;
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
-        hipLaunchKernelGGL(bwt_inverse_walk_count_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
+        const char* ev = getenv("BWTGPU_WALK_LDS");
+        const size_t walk_lds = ev ? (size_t)atoi(ev) : 0;
+        hipLaunchKernelGGL(bwt_inverse_walk_count_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), walk_lds, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bwt_inverse_walk_write_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
+        hipLaunchKernelGGL(bwt_inverse_walk_write_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), walk_lds, s, a);
         HIP_TRY(hipGetLastError());
     }
     return BWTGPU_OK;
