@@ -420,7 +420,16 @@ __device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, 
     const uint32_t cntp = nthr * (uint32_t)V;
     up = 64 - kshift - bits;  // left shift that puts the key's top bit at bit 63
     bsub = base << kshift;
-    for (uint32_t i = tid; i < cntp; i += NT) ls[i] = i < cnt ? (g[i] - bsub) << up : ~0ull;
+    for (uint32_t i0 = tid; i0 < cntp; i0 += 8 * NT) {  // eight loads in flight per thread
+        uint64_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = g[min(i0 + (uint32_t)(u * NT), cnt - 1u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + (uint32_t)(u * NT);
+            if (i < cntp) ls[i] = i < cnt ? (x[u] - bsub) << up : ~0ull;
+        }
+    }
     if (bits <= 32) lds_sort_passes<NT, true>(nthr, bits, up, sh);
     else lds_sort_passes<NT, false>(nthr, bits, up, sh);
 }
