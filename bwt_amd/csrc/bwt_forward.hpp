@@ -508,30 +508,41 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit&
     ck.init(r.n, W);
     const int kshift = r.ibits + 8;
     const int lead = kMaxM0 - r.m0;  // steps whose symbols would be shifted out anyway
+    // the global loads of a tile: 7 aligned dwords that cover the 24 window bytes at any alignment
+    // and (MODE 1) 3 that cover the 8 bytes preceding the lane's positions
+    uint32_t nraw[7], npw[3] = {0u, 0u, 0u};
+    auto fetch = [&](uint32_t tile) {
+        const uint32_t q0 = tile + (uint32_t)(kRun * lane);
+        const uint8_t* wp = r.s + ((int64_t)q0 + r.m0 - kMaxM0);  // text position of window byte 0
+        const uint8_t* ap = wp - (reinterpret_cast<uintptr_t>(wp) & 3u);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) nraw[j] = load_dword_guarded(ap + 4 * j, r.g_lo, r.g_hi);
+        if (MODE == 1) {
+            const uint8_t* pp = r.s + (int64_t)q0 - 1;
+            const uint8_t* pa = pp - (reinterpret_cast<uintptr_t>(pp) & 3u);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) npw[j] = load_dword_guarded(pa + 4 * j, r.g_lo, r.g_hi);
+        }
+    };
+    if (lo < hi) fetch(lo);
     for (uint32_t tile = lo; tile < hi; tile += kTile) {
         const uint32_t q0 = tile + (uint32_t)(kRun * lane);
-        const int64_t wstart = (int64_t)q0 + r.m0 - kMaxM0;  // text position of window byte 0
-        // 7 aligned dwords cover the 24 window bytes at any alignment
-        const uint8_t* wp = r.s + wstart;
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(wp) & 3u);
-        const uint8_t* ap = wp - mis;
-        uint32_t raw[7];
+        uint32_t raw[7], pw[3];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) raw[j] = load_dword_guarded(ap + 4 * j, r.g_lo, r.g_hi);
+        for (int j = 0; j < 7; ++j) raw[j] = nraw[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pw[j] = npw[j];
+        if (tile + kTile < hi) fetch(tile + kTile);  // the next tile's loads fly while this one is processed
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(r.s + ((int64_t)q0 + r.m0 - kMaxM0)) & 3u);
         uint32_t win[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) win[j] = __builtin_amdgcn_alignbyte(raw[j + 1], raw[j], mis);
         // the 8 bytes that precede positions q0 .. q0+7 (text positions q0-1 .. q0+6)
         uint32_t prevw[2] = {0u, 0u};
         if (MODE == 1) {
-            const uint8_t* pp = r.s + (int64_t)q0 - 1;
-            const uint32_t pmis = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3u);
-            const uint8_t* pa = pp - pmis;
-            const uint32_t p0 = load_dword_guarded(pa, r.g_lo, r.g_hi);
-            const uint32_t p1 = load_dword_guarded(pa + 4, r.g_lo, r.g_hi);
-            const uint32_t p2 = load_dword_guarded(pa + 8, r.g_lo, r.g_hi);
-            prevw[0] = __builtin_amdgcn_alignbyte(p1, p0, pmis);
-            prevw[1] = __builtin_amdgcn_alignbyte(p2, p1, pmis);
+            const uint32_t pmis = (uint32_t)(reinterpret_cast<uintptr_t>(r.s + (int64_t)q0 - 1) & 3u);
+            prevw[0] = __builtin_amdgcn_alignbyte(pw[1], pw[0], pmis);
+            prevw[1] = __builtin_amdgcn_alignbyte(pw[2], pw[1], pmis);
         }
         uint64_t key = 0;
         uint64_t el[kRun];
@@ -590,18 +601,28 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit&
                 if ((valid_bits >> j) & 1u) tin[tcnt[dj[j]] + rk[j]] = el[j];
             compiler_fence();
             uint32_t* nhist = sh.hist[sel ^ 1];
-            for (uint32_t i0 = 0; i0 < total; i0 += kWave) {
-                const uint32_t i = i0 + lane;
-                if (i < total) {
-                    const uint64_t x = tin[i];
-                    const uint32_t pos = tdel[dig(x)] + i;
-                    if (pos < r.n) {
-                        dst[pos] = x;
-                        if (has_next) atomicAdd(&nhist[ck.wave_of(pos) * kBins + nxt(x)], 1u);
-                    } else {
-                        atomicOr(err, kErrBounds);  // unreachable unless the histogram is inconsistent
-                    }
+            uint64_t x[kRun];
+            uint32_t pos[kRun];
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) x[u] = tin[u * kWave + lane];  // slots past `total` hold stale data, unused
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) pos[u] = dig(x[u]);
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) pos[u] = tdel[pos[u]] + (uint32_t)(u * kWave + lane);
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) {
+                if ((uint32_t)(u * kWave + lane) < total) {
+                    if (pos[u] < r.n) dst[pos[u]] = x[u];
+                    else bad = true;  // unreachable unless the histogram is inconsistent
                 }
+            }
+            if (bad) atomicOr(err, kErrBounds);
+            if (has_next) {
+#pragma unroll
+                for (int u = 0; u < kRun; ++u)
+                    if ((uint32_t)(u * kWave + lane) < total && pos[u] < r.n)
+                        atomicAdd(&nhist[ck.wave_of(pos[u]) * kBins + nxt(x[u])], 1u);
             }
             compiler_fence();
         }
