@@ -992,24 +992,47 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
 
 // Rank of suffix j by its first m0 symbols = number of round-0 elements with a smaller key:
 // binary search in the sorted round-0 array (used while the rank array holds survivors only).
-__device__ __forceinline__ uint32_t rank_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
-                                                   const uint8_t* sym, uint32_t j) {
-    uint64_t key = 0;
+// U suffixes at a time; positions j >= n are tolerated (their result is meaningless).
+template <int U>
+__device__ __forceinline__ void ranks_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
+                                                const uint8_t* sym, const uint32_t (&j)[U], uint32_t (&out)[U]) {
+    uint64_t key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) key[u] = 0;
     for (int t = 0; t < r.m0; ++t) {
-        const uint32_t p = j + (uint32_t)t;
-        uint32_t c = 0;
-        if (p < r.len) c = (uint32_t)sym[r.s[p]] + 1u;
-        else if (p == r.len) c = r.dcode;
-        key = (key << r.sbits) | c;
+        uint32_t byte[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) byte[u] = r.s[min(j[u] + (uint32_t)t, r.len - 1u)];  // len >= 1 here
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = j[u] + (uint32_t)t;
+            uint32_t c = (uint32_t)sym[byte[u]] + 1u;
+            if (p >= r.len) c = (p == r.len) ? r.dcode : 0u;
+            key[u] = (key[u] << r.sbits) | c;
+        }
     }
     const int kshift = r.ibits + 8;
-    uint32_t lo = 0, hi = r.n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((sorted0[mid] >> kshift) < key) lo = mid + 1;
-        else hi = mid;
+    uint32_t lo[U], hi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        lo[u] = 0;
+        hi[u] = r.n;
     }
-    return lo;
+    for (int it = 0; it <= r.ibits; ++it) {  // the range halves every step: ibits + 1 steps empty it
+        uint64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = sorted0[min((lo[u] + hi[u]) >> 1, r.n - 1u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t mid = (lo[u] + hi[u]) >> 1;
+            if (lo[u] < hi[u]) {
+                if ((v[u] >> kshift) < key[u]) lo[u] = mid + 1;
+                else hi[u] = mid;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) out[u] = lo[u];
 }
 
 template <int NT>
@@ -1174,16 +1197,42 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             const uint32_t dmask = (1u << plan.bits(0)) - 1u;
             const uint64_t imask = (1ull << ibits) - 1ull;
             uint32_t* myhist = sh.hist[0] + w * kBins;
-            for (uint32_t base = lo; base < hi; base += kWave) {
-                const uint32_t k = base + lane;
-                if (k < hi) {
-                    uint64_t e = alt[k];
-                    const uint32_t j = (uint32_t)(e & imask) + h;
-                    uint32_t r2 = 0u;
-                    if (j < n) r2 = (full ? rank[j] : rank_by_search(sorted0, r0, sh.sym, j)) + 1u;
-                    e |= (uint64_t)r2 << ibits;
-                    alt[k] = e;
-                    atomicAdd(&myhist[(uint32_t)(e >> ibits) & dmask], 1u);
+            if (full) {
+                for (uint32_t base = lo; base < hi; base += kWave) {
+                    const uint32_t k = base + lane;
+                    if (k < hi) {
+                        uint64_t e = alt[k];
+                        const uint32_t j = (uint32_t)(e & imask) + h;
+                        const uint32_t r2 = j < n ? rank[j] + 1u : 0u;
+                        e |= (uint64_t)r2 << ibits;
+                        alt[k] = e;
+                        atomicAdd(&myhist[(uint32_t)(e >> ibits) & dmask], 1u);
+                    }
+                }
+            } else {
+                // ranks by binary search in the sorted round-0 array: four searches per lane run
+                // side by side, so their dependent loads overlap
+                constexpr int U = 4;
+                for (uint32_t base = lo; base < hi; base += U * kWave) {
+                    uint64_t e[U];
+                    uint32_t j[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        e[u] = alt[min(base + (uint32_t)(u * kWave + lane), m - 1u)];
+                        j[u] = (uint32_t)(e[u] & imask) + h;
+                    }
+                    uint32_t rk[U];
+                    ranks_by_search<U>(sorted0, r0, sh.sym, j, rk);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t k = base + (uint32_t)(u * kWave + lane);
+                        if (k < hi) {
+                            const uint32_t r2 = j[u] < n ? rk[u] + 1u : 0u;
+                            const uint64_t x = e[u] | ((uint64_t)r2 << ibits);
+                            alt[k] = x;
+                            atomicAdd(&myhist[(uint32_t)(x >> ibits) & dmask], 1u);
+                        }
+                    }
                 }
             }
         }
