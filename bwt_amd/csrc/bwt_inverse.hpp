@@ -18,15 +18,18 @@
 // memory system idle, so a well-formed block (exactly one delimiter) is cut into segments:
 // every kSplitStride-th row and the delimiter row are "splitters"; one lane per splitter
 // walks until it reaches the next splitter (whose own byte still belongs to it).
-//   bwt_inverse_walk_count_kernel   every segment's length and the splitter it runs into
-//   bwt_inverse_stitch_kernel       orders the segments by following those links from the
-//                                   delimiter row: where each segment's bytes go
-//   bwt_inverse_walk_write_kernel   walks every segment again and writes its bytes in place
-// Walking twice is cheaper than walking once through HBM: the lanes of a block are placed on
-// ONE XCD (workgroup w runs on XCD w % 8), and with a splitter every 32 rows a block brings
-// enough lanes that an XCD works on only a few blocks at a time, whose LF tables (4 bytes per
-// row) then stay in that XCD's 4 MiB L2: a dependent random load costs an L2 hit instead of a
-// 64-byte HBM transaction.  The result is the chain the reference walks, byte for byte.
+//   bwt_inverse_walk_segments_kernel  every segment's length, the splitter it runs into and its
+//                                     bytes (into a 128-byte staging slot per segment; the few
+//                                     longer ones chain chunks from a per-block pool)
+//   bwt_inverse_stitch_kernel         orders the segments by following those links from the
+//                                     delimiter row: where each segment's bytes go
+//   bwt_inverse_place_kernel          copies every segment, reversed, to its place
+// The lanes of a block are placed on ONE XCD (workgroup w runs on XCD w % 8), and with a
+// splitter every 32 rows a block brings enough lanes that an XCD works on only a few blocks at
+// a time, whose LF tables (4 bytes per row) then largely stay in that XCD's 4 MiB L2: a
+// dependent random load costs an L2 hit instead of a 64-byte HBM transaction.  The staging
+// stores bypass the L2 so they do not evict the tables.  The result is the chain the reference
+// walks, byte for byte.
 // Blocks with several delimiters (only possible for hand-made input) keep the reference's
 // exact semantics -- start at the last delimiter row, stop at the first delimiter reached --
 // through the single-chain kernel (bwt_inverse_walk_kernel), as do blocks too short to split.
@@ -42,6 +45,7 @@ constexpr uint32_t kSplitFlag = 0x00800000u; // this row starts a segment
 constexpr uint32_t kSplitStride = 32;        // rows between regular splitters
 constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain
 constexpr int kSegThreads = 256;             // workgroup size of the segment kernels
+constexpr uint32_t kSlot = 128;              // bytes of staging per segment; longer segments chain pool chunks of the same size
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 constexpr uint32_t kModeMulti = 0, kModeSingle = 1, kModeNone = 2;
 
@@ -60,6 +64,12 @@ struct InvArgs {
     uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
     uint2* seg;           // nblocks * seg_cap: x = bytes the segment produces, y = id of the splitter it runs into
     uint32_t* seg_pos;    // nblocks * seg_cap: bytes between the segment's first byte and the text end
+    uint8_t* stage;       // nblocks * seg_cap * kSlot: the first kSlot bytes of every segment, in walk order
+    uint32_t* seg_ovf;    // nblocks * seg_cap: first pool chunk of a segment longer than kSlot (valid only then)
+    uint32_t chunk_cap;   // pool chunks per block
+    uint32_t* pool_used;  // per block: chunks handed out
+    uint32_t* chunk_next; // nblocks * chunk_cap: the chunk that follows (valid only if the segment goes on)
+    uint8_t* pool;        // nblocks * chunk_cap * kSlot
     uint32_t* lens;       // per block: text length or BWTGPU_LEN_NO_DELIMITER
     uint32_t* queue;      // [0] next block index to hand out
 };
@@ -154,6 +164,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         if (tid == 0) {
             a.drow[b] = drow;
             a.mode[b] = mode;
+            a.pool_used[b] = 0;
         }
         const bool split = mode == kModeMulti;
         // pass 2: LF table
@@ -266,7 +277,9 @@ __device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, u
     return b < a.nblocks && a.mode[b] == kModeMulti;
 }
 
-__global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_count_kernel(InvArgs a) {
+// Walks every segment once: its length, the splitter it runs into, and its bytes -- in walk
+// order, 16 at a time -- into the segment's staging slot (then chained pool chunks).
+__global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(InvArgs a) {
     uint32_t b, j;
     if (!segment_of_lane(a, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
@@ -281,18 +294,53 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_count_kernel(Inv
         return;
     }
     const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    const uint64_t pb = (uint64_t)b * a.chunk_cap;
+    uint8_t* buf = a.stage + (sb + j) * kSlot;
+    uint32_t prevc = 0;
     uint32_t row = T[start] & kRowMask;
     uint32_t t = 0;  // bytes the segment produces
+    uint32_t acc = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     uint32_t stop = start;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     for (uint32_t step = 0; step < n; ++step) {
         const uint32_t wd = T[row];
-        if (wd & kSplitFlag) {
+        const bool at_splitter = (wd & kSplitFlag) != 0u;
+        if (at_splitter && row == drow) {  // the delimiter row ends the text and has no byte
             stop = row;
-            if (row != drow) ++t;  // a splitter's own byte belongs to the segment that reaches it;
-            break;                 // the delimiter row ends the text and has no byte
+            break;
         }
+        if (t && (t & (kSlot - 1u)) == 0u) {  // the slot (or chunk) is full: chain a pool chunk
+            const uint32_t c = atomicAdd(&a.pool_used[b], 1u);
+            if (c >= a.chunk_cap) break;  // cannot happen: the pool holds n / kSlot + 8 chunks
+            if (t == kSlot) a.seg_ovf[sb + j] = c;
+            else a.chunk_next[pb + prevc] = c;
+            prevc = c;
+            buf = a.pool + (pb + c) * kSlot;
+        }
+        acc |= (wd >> 24) << (8u * (t & 3u));
         ++t;
+        if ((t & 3u) == 0u) {
+            q0 = q1; q1 = q2; q2 = q3; q3 = acc;
+            acc = 0;
+            if ((t & 15u) == 0u) {
+                const v4 val = {q0, q1, q2, q3};
+                __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t - 16u) & (kSlot - 1u))));
+            }
+        }
+        if (at_splitter) {  // a splitter's own byte belongs to the segment that reaches it
+            stop = row;
+            break;
+        }
         row = wd & kRowMask;
+    }
+    if (t & 15u) {  // flush the partial 16-byte group (the slot has room; bytes past t are never used)
+        const uint32_t have = (t & 15u) >> 2;  // complete dwords in the group: q3 newest
+        v4 val = {0u, 0u, 0u, 0u};
+        if (have == 0) { val.x = acc; }
+        else if (have == 1) { val.x = q3; val.y = acc; }
+        else if (have == 2) { val.x = q2; val.y = q3; val.z = acc; }
+        else { val.x = q1; val.y = q2; val.z = q3; val.w = acc; }
+        __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t & ~15u) & (kSlot - 1u))));
     }
     a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : stop / kSplitStride);
 }
@@ -412,7 +460,9 @@ struct BackWriter {
     }
 };
 
-__global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_write_kernel(InvArgs a) {
+// Moves every chained segment from its staging slot (and pool chunks) to its place: the bytes
+// were produced back to front, so byte t of the segment lands t + 1 bytes below its upper end.
+__global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
     uint32_t b, j;
     if (!segment_of_lane(a, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
@@ -423,15 +473,23 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_write_kernel(Inv
     if (pos == kNoPos) return;  // a segment on a cycle the delimiter's chain never reaches
     const uint32_t len = a.seg[sb + j].x;
     if ((uint64_t)pos + len > (uint64_t)(n - 1)) return;  // never: the chain is at most n-1 bytes long
-    const uint32_t start = j < nreg ? j * kSplitStride : a.drow[b];
-    const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    const uint64_t pb = (uint64_t)b * a.chunk_cap;
+    const uint8_t* src = a.stage + (sb + j) * kSlot;
+    uint32_t c = 0;
     BackWriter bw;
     bw.init(a.out + (uint64_t)b * a.block_size + (n - 1) - pos);
-    uint32_t row = T[start] & kRowMask;
-    for (uint32_t step = 0; step < len; ++step) {
-        const uint32_t wd = T[row];
-        bw.push(wd >> 24);
-        row = wd & kRowMask;
+    for (uint32_t p = 0; p < len; p += 16u) {
+        if (p && (p & (kSlot - 1u)) == 0u) {
+            c = p == kSlot ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
+            if (c >= a.chunk_cap) break;  // never
+            src = a.pool + (pb + c) * kSlot;
+        }
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (p & (kSlot - 1u)));
+        const uint32_t m = min(16u, len - p);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((uint32_t)k < m) bw.push((wds[k >> 2] >> (8 * (k & 3))) & 255u);
     }
     bw.flush();
 }

@@ -109,9 +109,9 @@ struct InvGeom {
     size_t nblocks;
     uint32_t tstride;
     uint32_t build_grid;
-    uint32_t seg_cap, seg_wgs;
+    uint32_t seg_cap, seg_wgs, chunk_cap;
     bool split;  // blocks are long enough for the segmented walk
-    size_t drow_off, mode_off, seg_off, segpos_off, t_off, bytes;
+    size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
 
 InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
@@ -125,6 +125,7 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.split = longest >= kMultiMinRows;
     g.seg_cap = g.split ? regular_splitters((uint32_t)longest) + 1u : 1u;
     g.seg_wgs = (g.seg_cap + kSegThreads - 1) / kSegThreads;
+    g.chunk_cap = g.split ? (uint32_t)(longest / kSlot) + 8u : 1u;
     size_t off = kHeaderBytes;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -133,8 +134,13 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     };
     g.drow_off = take(g.nblocks * 4);
     g.mode_off = take(g.nblocks * 4);
+    g.used_off = take(g.nblocks * 4);
     g.seg_off = take(g.nblocks * g.seg_cap * 8);
     g.segpos_off = take(g.nblocks * g.seg_cap * 4);
+    g.segovf_off = take(g.nblocks * g.seg_cap * 4);
+    g.next_off = take(g.nblocks * (size_t)g.chunk_cap * 4);
+    g.stage_off = take(g.split ? g.nblocks * (size_t)g.seg_cap * kSlot : 0);
+    g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * kSlot : 0);
     g.t_off = take((size_t)g.tstride * 4 * g.nblocks);
     g.bytes = off;
     return g;
@@ -439,6 +445,12 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.mode = (uint32_t*)(ws + g.mode_off);
     a.seg = (uint2*)(ws + g.seg_off);
     a.seg_pos = (uint32_t*)(ws + g.segpos_off);
+    a.stage = ws + g.stage_off;
+    a.seg_ovf = (uint32_t*)(ws + g.segovf_off);
+    a.chunk_cap = g.chunk_cap;
+    a.pool_used = (uint32_t*)(ws + g.used_off);
+    a.chunk_next = (uint32_t*)(ws + g.next_off);
+    a.pool = ws + g.pool_off;
     a.lens = d_out_lens;
     a.queue = (uint32_t*)d_workspace;
     hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
@@ -449,13 +461,11 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     if (g.split) {
         const uint64_t wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * g.seg_wgs;
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
-        const char* ev = getenv("BWTGPU_WALK_LDS");
-        const size_t walk_lds = ev ? (size_t)atoi(ev) : 0;
-        hipLaunchKernelGGL(bwt_inverse_walk_count_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), walk_lds, s, a);
+        hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bwt_inverse_walk_write_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), walk_lds, s, a);
+        hipLaunchKernelGGL(bwt_inverse_place_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     return BWTGPU_OK;
