@@ -448,6 +448,24 @@ struct BackWriter {
             cnt = 0;
         }
     }
+    // Four bytes at once: v's low byte goes to the lowest address.  Only at a dword boundary.
+    __device__ __forceinline__ void push_dword(uint32_t v) {
+        addr -= 4;
+        q3 = q2; q2 = q1; q1 = q0; q0 = v;
+        daddr = addr;
+        ++dcnt;
+        if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
+            if (dcnt == 4) {
+                *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
+            } else {
+                uint32_t* d = reinterpret_cast<uint32_t*>(addr);
+                d[0] = q0;
+                if (dcnt > 1) d[1] = q1;
+                if (dcnt > 2) d[2] = q2;
+            }
+            dcnt = 0;
+        }
+    }
     __device__ __forceinline__ void flush() {
         for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
         if (dcnt) {
@@ -478,18 +496,42 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     uint32_t c = 0;
     BackWriter bw;
     bw.init(a.out + (uint64_t)b * a.block_size + (n - 1) - pos);
-    for (uint32_t p = 0; p < len; p += 16u) {
-        if (p && (p & (kSlot - 1u)) == 0u) {
-            c = p == kSlot ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
+    // Source byte t goes to address end - 1 - t.  The bytes down to the first dword boundary go
+    // one by one; from there every aligned destination dword is four consecutive source bytes
+    // reversed: an unaligned source dword (funnel shift over two aligned ones) byte-swapped.
+    const uint32_t head = min(len, (uint32_t)(reinterpret_cast<uintptr_t>(bw.addr) & 3u));
+    const uint32_t nd = (len - head) >> 2;           // whole destination dwords
+    const uint32_t tail = len - head - 4u * nd;      // bytes below the last whole dword
+    const uint32_t last_group = (nd + 1u) >> 2;      // source dwords 0 .. nd+1 are consulted
+    uint32_t prev = 0;
+    for (uint32_t g = 0; g <= last_group; ++g) {
+        if (g && (g & (kSlot / 16u - 1u)) == 0u && 16u * g < len) {  // the next chunk of a long segment
+            c = g == kSlot / 16u ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
             if (c >= a.chunk_cap) break;  // never
             src = a.pool + (pb + c) * kSlot;
         }
-        const uint4 v = *reinterpret_cast<const uint4*>(src + (p & (kSlot - 1u)));
-        const uint32_t m = min(16u, len - p);
-        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + ((16u * g) & (kSlot - 1u)));
+        if (g == 0) {
+            for (uint32_t k = 0; k < head; ++k) bw.push((v.x >> (8u * k)) & 255u);
+        }
+        const uint32_t lo[4] = {prev, v.x, v.y, v.z}, hi[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if ((uint32_t)k < m) bw.push((wds[k >> 2] >> (8 * (k & 3))) & 255u);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t d = 4u * g + (uint32_t)k - 1u;  // destination dword this pair yields (g = 0, k = 0: none)
+            if (d <= nd && !(g == 0 && k == 0)) {
+                uint32_t w = lo[k];  // source bytes head + 4 d ..
+                if (head == 1) w = __builtin_amdgcn_alignbyte(hi[k], lo[k], 1);
+                else if (head == 2) w = __builtin_amdgcn_alignbyte(hi[k], lo[k], 2);
+                else if (head == 3) w = __builtin_amdgcn_alignbyte(hi[k], lo[k], 3);
+                if (d < nd) {
+                    bw.push_dword(__builtin_bswap32(w));
+                } else {
+                    for (uint32_t u = 0; u < tail; ++u) bw.push((w >> (8u * u)) & 255u);
+                }
+            }
+        }
+        prev = v.w;
     }
     bw.flush();
 }
