@@ -7,8 +7,8 @@
 // that runs past the end is smaller (src/bwt.cpp:66-80).
 //
 // Algorithm (per block, n = len + 1 symbols including the appended delimiter)
-//   0. census: which byte values occur -> dense order-preserving codes 1..sigma
-//      (0 is reserved for "past the end"), sbits = bits per code.
+//   0. census: which byte values occur in the text -> dense order-preserving codes
+//      0..sigma-1, sbits = bits per code (the delimiter and the end get no code: round0_key).
 //   1. round 0: element i = (first m0 codes of suffix i, packed) << ibits | i, built by
 //      a rolling window over the input bytes; LSD radix sort of all n elements on the key.
 //      The first pass needs no stability, so the keys are generated straight into it and
@@ -108,6 +108,7 @@ struct FwdShared {
     uint8_t sym[256];               // byte value -> code
     uint32_t wsum[W];
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
+    uint32_t tailrow[kMaxM0 + 1];   // final rows of the suffixes that reach the delimiter within m0 symbols
     uint32_t blk;
 };
 
@@ -468,12 +469,36 @@ struct Round0 {
     const uint8_t* g_lo;   // readable byte range of the whole batch buffer: [g_lo, g_hi)
     const uint8_t* g_hi;
     uint32_t len, n;
-    uint32_t dcode;        // code of the delimiter
+    uint32_t nm;           // suffixes 0 .. nm-1 have m0 text symbols ahead of them ("main"), the rest reach the delimiter ("tails")
+    uint32_t dcode;        // what the delimiter position contributes to a tail's key
+    uint32_t pad;          // what positions past the delimiter contribute
+    uint32_t above;        // 1: the delimiter is larger than every text byte and does not fit a symbol field
     uint32_t delim;        // the delimiter byte itself
     int m0, sbits, ibits;
-    int fshift;            // key >> fshift = fine bin
+    int fshift;            // full key >> fshift = fine bin
     uint64_t kmask;        // m0*sbits low bits
 };
+
+// Round-0 keys.  Text symbols get dense order-preserving codes 0..sigma-1 (sbits bits each; the
+// delimiter and "past the end" get none, which keeps e.g. ACGT at 2 bits per symbol).  K = the
+// first m0 symbols packed.  A main suffix has key 2K+1.  A tail -- P (q < m0 text symbols), the
+// delimiter, nothing -- sorts after every main suffix whose K is below V = pack(P, dr, 0..0) and
+// before all others, where dr = number of text byte values below the delimiter (its code if it
+// occurs in the text): that is src/bwt.cpp:66-80's order, the delimiter comparing by byte value
+// and the end of the string comparing low.  So a tail gets the even key 2V.  When dr does not fit
+// a symbol field (the delimiter is above all 2^sbits text symbols) the tail sorts after every
+// main suffix with prefix P instead: key 2(pack(P, 1..1) + 1).  Tails with equal keys (a run of
+// the smallest or largest symbol before the delimiter) are ordered by length in the next round.
+__device__ __forceinline__ uint64_t round0_key(const Round0& r, uint64_t packed, uint32_t pos) {
+    return pos < r.nm ? 2ull * packed + 1ull : 2ull * (packed + r.above);
+}
+
+// Tails whose round-0 keys tie are told apart in the next round by this value in place of a
+// rank: the shorter suffix first when the delimiter orders low, the longer one when it orders
+// above every symbol (see round0_key).  1 .. m0.
+__device__ __forceinline__ uint32_t tail_order(const Round0& r, uint32_t idx) {
+    return r.above ? idx - r.nm + 1u : r.n - idx;
+}
 
 __device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* p, const uint8_t* g_lo, const uint8_t* g_hi) {
     if (p >= g_lo && p + 4 <= g_hi) return *reinterpret_cast<const uint32_t*>(p);
@@ -552,20 +577,20 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit&
             if (t >= lead) {  // wave-uniform
                 const uint32_t pos = q0 + (uint32_t)(t - lead);  // = wstart + t, never negative here
                 const uint32_t byte = (win[t >> 2] >> (8 * (t & 3))) & 255u;
-                uint32_t c = (uint32_t)sh.sym[byte] + 1u;
-                if (pos >= r.len) c = (pos == r.len) ? r.dcode : 0u;
+                uint32_t c = (uint32_t)sh.sym[byte];
+                if (pos >= r.len) c = (pos == r.len) ? r.dcode : r.pad;
                 key = ((key << r.sbits) | c) & r.kmask;
             }
             if (t >= 16) {
                 const int j = t - 16;
                 const uint32_t pe = q0 + (uint32_t)j;
                 const bool valid = pe < hi;
-                if (MODE == 0) {
-                    if (valid) atomicAdd(&sh.u.fine[(uint32_t)(key >> r.fshift)], 1u);
+                if (MODE == 0) {  // main suffixes only (short window); the tails are counted by count_tails
+                    if (valid && pe < r.nm) atomicAdd(&sh.u.fine[(uint32_t)((2ull * key + 1ull) >> r.fshift)], 1u);
                 } else {
                     uint32_t prev = (prevw[j >> 2] >> (8 * (j & 3))) & 255u;
                     if (pe == 0) prev = r.delim;  // the row of suffix 0 carries the delimiter (src/bwt.cpp:115-116)
-                    el[j] = (key << kshift) | ((uint64_t)prev << r.ibits) | pe;
+                    el[j] = (round0_key(r, key, pe) << kshift) | ((uint64_t)prev << r.ibits) | pe;
                     if (valid) valid_bits |= 1u << j;
                 }
             }
@@ -994,9 +1019,8 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
 // binary search in the sorted round-0 array (used while the rank array holds survivors only).
 // U suffixes at a time; positions j >= n are tolerated (their result is meaningless).
 template <int U>
-__device__ __forceinline__ void ranks_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
-                                                const uint8_t* sym, const uint32_t (&j)[U], uint32_t (&out)[U]) {
-    uint64_t key[U];
+__device__ __forceinline__ void suffix_keys(const Round0& r, const uint8_t* sym, const uint32_t (&j)[U],
+                                            uint64_t (&key)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) key[u] = 0;
     for (int t = 0; t < r.m0; ++t) {
@@ -1006,11 +1030,20 @@ __device__ __forceinline__ void ranks_by_search(const uint64_t* __restrict__ sor
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t p = j[u] + (uint32_t)t;
-            uint32_t c = (uint32_t)sym[byte[u]] + 1u;
-            if (p >= r.len) c = (p == r.len) ? r.dcode : 0u;
+            uint32_t c = (uint32_t)sym[byte[u]];
+            if (p >= r.len) c = (p == r.len) ? r.dcode : r.pad;
             key[u] = (key[u] << r.sbits) | c;
         }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) key[u] = round0_key(r, key[u], j[u]);
+}
+
+template <int U>
+__device__ __forceinline__ void ranks_by_search(const uint64_t* __restrict__ sorted0, const Round0& r,
+                                                const uint8_t* sym, const uint32_t (&j)[U], uint32_t (&out)[U]) {
+    uint64_t key[U];
+    suffix_keys<U>(r, sym, j, key);
     const int kshift = r.ibits + 8;
     uint32_t lo[U], hi[U];
 #pragma unroll
@@ -1053,19 +1086,23 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     if (tid < 256) sh.sym[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < len; i += NT) sh.sym[s[i]] = 1;  // all writers store the same value
-    if (tid == 0) sh.sym[delim] = 1;
     __syncthreads();
     const uint32_t present = tid < 256 ? sh.sym[tid] : 0;
-    uint32_t sigma;
+    uint32_t sigma;  // distinct byte values in the text (the appended delimiter is not one of them)
     const uint32_t below = block_exclusive_scan<NT>(present, sh.wsum, sigma);
-    if (tid < 256) sh.sym[tid] = (uint8_t)below;  // code - 1 (codes run 1..sigma; 0 = past the end)
-    const int sbits = bit_length(sigma);
+    if (tid < 256) sh.sym[tid] = (uint8_t)below;  // code of a text byte; for an absent byte: how many text bytes are below it
+    __syncthreads();
+    const int sbits = max(1, bit_length(sigma - 1u));
     const int ibits = bit_length(n - 1);
-    int m0 = (2 * ibits) / sbits;
-    const int m0cap = min((64 - 8 - ibits) / sbits, kMaxM0);
+    // about 4/3 ibits bits of symbol information per key: sized as if the codes also had to
+    // represent the delimiter and the end (bit_length(sigma + 1) bits per symbol)
+    int m0 = (2 * ibits) / bit_length(sigma + 1u);
+    const int m0cap = min((64 - 8 - ibits - 2) / sbits, kMaxM0);
     if (m0 > m0cap) m0 = m0cap;
     if (m0 < 1) m0 = 1;
-    const int kbits = m0 * sbits;
+    const uint32_t dr = sh.sym[delim];
+    const uint32_t above = dr == (1u << sbits) ? 1u : 0u;
+    const int kbits = m0 * sbits + 1 + (int)above;
     const int fbits = min(kbits, kFineBits);
     for (int i = tid; i < kFine; i += NT) sh.u.fine[i] = 0;
     __syncthreads();
@@ -1080,21 +1117,32 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     r0.g_hi = a.in + a.total_len;
     r0.len = len;
     r0.n = n;
-    r0.dcode = (uint32_t)sh.sym[delim] + 1u;
+    r0.nm = len >= (uint32_t)m0 ? len - (uint32_t)m0 + 1u : 0u;
+    r0.above = above;
+    r0.dcode = above ? (1u << sbits) - 1u : dr;
+    r0.pad = above ? (1u << sbits) - 1u : 0u;
     r0.delim = delim;
     r0.m0 = m0;
     r0.sbits = sbits;
     r0.ibits = ibits;
     r0.fshift = kbits - fbits;
-    r0.kmask = (1ull << kbits) - 1ull;
+    r0.kmask = (1ull << (m0 * sbits)) - 1ull;
     const int kshift0 = ibits + 8;
     BucketDigit dig{sh.v.lut, kshift0 + r0.fshift, 0, 0u}, dig2 = dig;
-    {   // the fine bin only needs the first few symbols of the key: a shorter window
+    {   // the fine bin of a main suffix only needs the first few symbols of its key: a shorter window
         Round0 rc = r0;
-        rc.m0 = min(m0, (fbits + sbits - 1) / sbits);
+        rc.m0 = min(m0, (fbits - (int)above + sbits - 1) / sbits);
         rc.kmask = (1ull << (rc.m0 * sbits)) - 1ull;
-        rc.fshift = rc.m0 * sbits - fbits;
+        rc.fshift = rc.m0 * sbits + 1 - (fbits - (int)above);  // applied to 2 K + 1
         round0_sweep<NT, 0>(rc, dig, dig2, false, nullptr, sh, 0, &queue[1]);
+        if (w == 0) {  // the tails (at most m0 <= 17): exact keys
+            const uint32_t jt[1] = {r0.nm + (uint32_t)lane};
+            if (jt[0] < n) {
+                uint64_t kt[1];
+                suffix_keys<1>(r0, sh.sym, jt, kt);
+                atomicAdd(&sh.u.fine[(uint32_t)(kt[0] >> r0.fshift)], 1u);
+            }
+        }
     }
     __syncthreads();
     pc.lap(1);
@@ -1174,6 +1222,35 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     if (!fused || m > n / 16u) rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, false, sh, m, G, full);
     pc.lap(3);
 
+    // Tails with equal round-0 keys are not told apart by their ranks yet although their first m0
+    // symbols differ (round0_key); the first doubling round needs their true order when it looks
+    // up rank[i + m0], so their final rows are worked out here: group start + the tied tails
+    // ahead of each.
+    if (w == 0) {
+        const uint32_t jt[1] = {min(r0.nm + (uint32_t)lane, n - 1u)};
+        const bool valid = r0.nm + (uint32_t)lane < n;
+        uint64_t kt[1];
+        suffix_keys<1>(r0, sh.sym, jt, kt);
+        uint32_t ahead = 0, tied = 0;
+        const uint32_t nt = n - r0.nm;
+        for (uint32_t t = 0; t < nt; ++t) {
+            const uint64_t other = __shfl(kt[0], (int)t);
+            if (other == kt[0] && t != (uint32_t)lane) {
+                ++tied;
+                if (r0.above ? t < (uint32_t)lane : t > (uint32_t)lane) ++ahead;
+            }
+        }
+        const bool any = __ballot(valid && tied) != 0ull;  // without ties the ranks are exact already
+        if (any) {
+            uint32_t rk[1];
+            ranks_by_search<1>(sorted0, r0, sh.sym, jt, rk);
+            if (valid) sh.tailrow[lane] = rk[0] + ahead;
+        }
+        if (lane == 0) sh.tailrow[kMaxM0] = any ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool tail_fix = sh.tailrow[kMaxM0] != 0u;
+
     // ---- 2. doubling rounds over the survivors -----------------------------------
     // Buffers: while `full` is false the sorted round-0 array must stay intact (ranks are
     // looked up in it), so the few survivors ping-pong inside the two halves of `spare`.
@@ -1186,6 +1263,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             break;
         }
         const int gbits = max(1, bit_length(G - 1));
+        const bool first = h == (uint32_t)m0;  // ranks still are round-0 ranks
         DigitPlan plan;
         plan.init(rbits + gbits);
         zero_hist<NT>(sh, 0);
@@ -1202,8 +1280,11 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
                     const uint32_t k = base + lane;
                     if (k < hi) {
                         uint64_t e = alt[k];
-                        const uint32_t j = (uint32_t)(e & imask) + h;
-                        const uint32_t r2 = j < n ? rank[j] + 1u : 0u;
+                        const uint32_t idx = (uint32_t)(e & imask);
+                        const uint32_t j = idx + h;
+                        uint32_t r2 = j < n ? rank[j] + 1u : 0u;
+                        if (tail_fix && first && j >= r0.nm && j < n) r2 = sh.tailrow[j - r0.nm] + 1u;
+                        if (idx >= r0.nm) r2 = tail_order(r0, idx);
                         e |= (uint64_t)r2 << ibits;
                         alt[k] = e;
                         atomicAdd(&myhist[(uint32_t)(e >> ibits) & dmask], 1u);
@@ -1227,7 +1308,9 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
                     for (int u = 0; u < U; ++u) {
                         const uint32_t k = base + (uint32_t)(u * kWave + lane);
                         if (k < hi) {
-                            const uint32_t r2 = j[u] < n ? rk[u] + 1u : 0u;
+                            uint32_t r2 = j[u] < n ? rk[u] + 1u : 0u;
+                            if (tail_fix && j[u] >= r0.nm && j[u] < n) r2 = sh.tailrow[j[u] - r0.nm] + 1u;  // this path only runs in the first round
+                            if (j[u] - h >= r0.nm) r2 = tail_order(r0, j[u] - h);
                             const uint64_t x = e[u] | ((uint64_t)r2 << ibits);
                             alt[k] = x;
                             atomicAdd(&myhist[(uint32_t)(x >> ibits) & dmask], 1u);
