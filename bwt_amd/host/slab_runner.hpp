@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <deque>
 #include <iostream>
+#include <mutex>
 #include <vector>
 
 #include "bwtgpu.h"
@@ -46,6 +47,56 @@ inline size_t slab_blocks_for(size_t unit_bytes, size_t file_bytes) {
     }
     return blocks;
 }
+
+// Creating a pipeline allocates pinned host slabs and device buffers, which costs milliseconds --
+// more than transforming a small file.  Callers that process many files (the performance
+// benchmark, a server) mostly repeat the same geometry, so the most recently used pipelines are
+// kept and handed out again (the operating system reclaims them at process exit).
+class PipelineCache {
+public:
+    static PipelineCache& instance() {
+        static PipelineCache* c = new PipelineCache;  // never destroyed: at exit the HIP runtime may be gone first
+        return *c;
+    }
+    bwtgpu_pipeline* acquire(int dev, int direction, size_t block_size, size_t slab_blocks, int depth) {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            for (size_t i = 0; i < idle_.size(); ++i) {
+                const Entry& e = idle_[i];
+                if (e.dev == dev && e.direction == direction && e.block_size == block_size &&
+                    e.slab_blocks == slab_blocks && e.depth == depth) {
+                    bwtgpu_pipeline* p = e.p;
+                    idle_.erase(idle_.begin() + (long)i);
+                    return p;
+                }
+            }
+        }
+        return bwtgpu_pipeline_create(dev, direction, block_size, slab_blocks, depth);
+    }
+    void release(bwtgpu_pipeline* p, int dev, int direction, size_t block_size, size_t slab_blocks, int depth) {
+        if (!p) return;
+        bwtgpu_pipeline* evict = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            idle_.push_back({p, dev, direction, block_size, slab_blocks, depth});
+            if (idle_.size() > kKeep) {
+                evict = idle_.front().p;
+                idle_.erase(idle_.begin());
+            }
+        }
+        bwtgpu_pipeline_destroy(evict);
+    }
+private:
+    struct Entry {
+        bwtgpu_pipeline* p;
+        int dev, direction;
+        size_t block_size, slab_blocks;
+        int depth;
+    };
+    static constexpr size_t kKeep = 4;
+    std::mutex mu_;
+    std::vector<Entry> idle_;
+};
 
 // Streams `processor`'s remaining input through the transform and writes the results.
 // unit = bytes one block occupies in the INPUT (block_size forward, block_size+1 inverse).
@@ -87,7 +138,7 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         if (inflight.size() == (size_t)ndev * (size_t)depth) drain_one();  // frees exactly (dev, slot)
         if (rc) break;
         if (!pipes[(size_t)dev]) {
-            pipes[(size_t)dev] = bwtgpu_pipeline_create(dev, direction, block_size, slab_blocks, depth);
+            pipes[(size_t)dev] = PipelineCache::instance().acquire(dev, direction, block_size, slab_blocks, depth);
             if (!pipes[(size_t)dev]) {
                 std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
                 rc = 1;
@@ -107,7 +158,10 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         if (got < cap) break;
     }
     while (!inflight.empty()) drain_one();
-    for (bwtgpu_pipeline* p : pipes) bwtgpu_pipeline_destroy(p);
+    for (size_t d = 0; d < pipes.size(); ++d) {
+        if (rc) bwtgpu_pipeline_destroy(pipes[d]);  // do not reuse a pipeline that reported an error
+        else PipelineCache::instance().release(pipes[d], (int)d, direction, block_size, slab_blocks, depth);
+    }
     return rc;
 }
 
