@@ -50,11 +50,19 @@ constexpr uint32_t kErrBounds = 2u;
 constexpr int kMaxM0 = 17;    // symbols per round-0 key (bounded by the 24-byte rolling window)
 constexpr int kRun = 8;       // consecutive positions one lane rolls through in round 0
 constexpr int kTile = kRun * kWave;  // positions per wave iteration in round 0
-constexpr int kTileVecs = 13;        // 64-element vectors a wave stages per tile in a radix pass (fits 3 workgroups' LDS per CU)
-constexpr int kTileElems = kTileVecs * kWave;
+// Sizes that depend on the workgroup size.  256 threads (three workgroups per CU) is the batch
+// configuration; 1024 threads (one workgroup per CU) serves inputs of only a few blocks, where a
+// block's latency is all that matters.
+template <int NT>
+struct FwdCfg {
+    // 64-element vectors a wave stages per tile in a radix pass (at least kRun: round 0 stages kRun vectors)
+    static constexpr int kTileVecs = NT <= 256 ? 13 : 8;
+    static constexpr int kTileElems = kTileVecs * kWave;
+    // elements per thread in an LDS bucket sort (odd, see lds_sort_bucket)
+    static constexpr int kSortVecs = NT <= 256 ? 19 : 5;
+};
 constexpr int kFineBits = 13;        // round 0: the top bits of the key that choose a fine bin
 constexpr int kFine = 1 << kFineBits;
-constexpr int kSortVecs = 19;        // elements per thread in an LDS bucket sort (odd, see lds_sort_bucket)
 constexpr int kLdsDigitBits = 4;     // digit width of the LDS bucket sort
 constexpr int kMaxBuckets = 256;     // round-0 buckets per block (bucket ids are bytes in the lookup table)
 constexpr size_t kBucketDirBytes = 2 * (kMaxBuckets + 1) * sizeof(uint32_t);  // bucket directory after the rank array
@@ -87,7 +95,9 @@ struct PhaseClock {
 template <int NT>
 struct FwdShared {
     static constexpr int W = NT / kWave;
-    static constexpr int kSortCap = NT * kSortVecs;  // largest bucket the LDS sort takes
+    static constexpr int kTileElems = FwdCfg<NT>::kTileElems;
+    static constexpr int kSortCap = NT * FwdCfg<NT>::kSortVecs;  // largest bucket the LDS sort takes
+    static_assert(FwdCfg<NT>::kTileVecs >= kRun && kTileElems <= 1024, "round 0 stages kRun vectors; tile ranks have 10 bits");
     struct Staging {
         uint64_t tin[W][kTileElems];    // per-wave staging tile, elements in arrival order
         uint16_t trk[W][kTileElems];    // per element: digit << 10 | rank among the tile's elements with that digit
@@ -260,6 +270,7 @@ __device__ __forceinline__ void radix_pass(const uint64_t* __restrict__ src, uin
     const uint32_t lo = (uint32_t)w * ck.chunk;
     const uint32_t hi = min(lo + ck.chunk, m);
     uint64_t* tin = sh.u.st.tin[w];
+    constexpr int kTileVecs = FwdCfg<NT>::kTileVecs, kTileElems = FwdCfg<NT>::kTileElems;
     constexpr int kHalf = (kTileVecs + 1) / 2;
     for (uint32_t base = lo; base < hi; base += kTileElems) {
         const uint32_t cnt = min((uint32_t)kTileElems, hi - base);
@@ -339,7 +350,7 @@ __device__ __forceinline__ void count_digits(const uint64_t* __restrict__ src, u
 // key has at most 32 bits (NARROW) every digit is a bit field of the high dword.
 template <int NT, bool NARROW>
 __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up, FwdShared<NT>& sh) {
-    constexpr int V = kSortVecs;
+    constexpr int V = FwdCfg<NT>::kSortVecs;
     const int tid = threadIdx.x;
     const bool active = (uint32_t)tid < nthr;
     const int P = (bits + kLdsDigitBits - 1) / kLdsDigitBits;
@@ -407,7 +418,7 @@ template <int NT>
 __device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, uint32_t cnt, int kshift,
                                                 uint64_t base, int bits, FwdShared<NT>& sh, int& up,
                                                 uint64_t& bsub) {
-    constexpr int V = kSortVecs;
+    constexpr int V = FwdCfg<NT>::kSortVecs;
     const int tid = threadIdx.x;
     uint64_t* ls = sh.u.lsort;
     up = 0;
@@ -1350,7 +1361,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT, 3) void bwt_forward_kernel(FwdArgs a) {
+__global__ __launch_bounds__(NT, NT <= 256 ? 3 : 4) void bwt_forward_kernel(FwdArgs a) {
     __shared__ FwdShared<NT> sh;
     uint64_t* bufA = reinterpret_cast<uint64_t*>(a.ws + (uint64_t)blockIdx.x * a.ws_stride);
     uint64_t* bufB = bufA + a.ncap;

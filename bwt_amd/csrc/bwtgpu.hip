@@ -18,6 +18,8 @@ namespace {
 
 using namespace bwtgpu;
 
+constexpr int kFwdWideThreads = 1024;  // forward, few-block inputs: one workgroup per CU
+constexpr size_t kWideMinBlock = 8192; // shorter blocks do not pay for the wide workgroup
 constexpr int kFwdThreads = 256;   // forward: threads per workgroup (4 waves, each with an 8 KiB LDS staging tile)
 constexpr int kInvThreads = 256;   // inverse table build: threads per workgroup
 constexpr size_t kHeaderBytes = 256;  // workspace header: work queue + status words
@@ -90,6 +92,7 @@ struct FwdGeom {
     uint32_t ncap;
     size_t stride;   // bytes of scratch per workgroup
     uint32_t grid;
+    bool wide;       // few blocks: 1024-thread workgroups, one per CU
     size_t bytes;    // whole workspace
 };
 
@@ -101,6 +104,9 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     g.stride = round_up((size_t)g.ncap * 20 + bwtgpu::kBucketDirBytes, 256);
     const size_t max_wgs = (size_t)d.cus * (size_t)d.fwd_wgs_per_cu;
     g.grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
+    // With fewer blocks than compute units most of the chip idles and a block's latency is the
+    // whole cost: give every block a 1024-thread workgroup instead.
+    g.wide = g.nblocks <= (size_t)d.cus && longest >= kWideMinBlock;
     g.bytes = kHeaderBytes + g.stride * g.grid;
     return g;
 }
@@ -405,7 +411,8 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     a.ws = (uint8_t*)d_workspace + kHeaderBytes;
     a.ws_stride = g.stride;
     a.queue = (uint32_t*)d_workspace;
-    hipLaunchKernelGGL(bwt_forward_kernel<kFwdThreads>, dim3(g.grid), dim3(kFwdThreads), 0, s, a);
+    if (g.wide) hipLaunchKernelGGL(bwt_forward_kernel<kFwdWideThreads>, dim3(g.grid), dim3(kFwdWideThreads), 0, s, a);
+    else hipLaunchKernelGGL(bwt_forward_kernel<kFwdThreads>, dim3(g.grid), dim3(kFwdThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
     return BWTGPU_OK;
 }

@@ -181,6 +181,10 @@ def test_skewed_distributions_and_many_blocks(orc):
     # 37 blocks of 8 KiB + ragged tail
     d = rng.integers(0, 255, size=37 * 8192 + 123, dtype=np.uint8)
     cases.append((d.tobytes(), 8192))
+    # more blocks than compute units: the 256-thread batch kernel (fewer blocks of this size get
+    # the 1024-thread one)
+    f = rng.integers(0, 4, size=300 * 16384 + 77, dtype=np.uint8) + 65
+    cases.append((f.tobytes(), 16384))
     # text-like: words from a small vocabulary
     vocab = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(50)]
     e = b" ".join(vocab[int(i)] for i in rng.integers(0, 50, size=60000))
