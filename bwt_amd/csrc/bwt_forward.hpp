@@ -72,7 +72,8 @@ constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition a
 // queue[16..] as u64: 0 census, 1 round-0 fine-bin count, 2 round-0 partition, 3 round-0 rerank
 // sweep (when not fused), 4 later key builds, 5 later sorts, 6 later reranks, 7 full-rank
 // rebuilds, 8 blocks, 9 later rounds, 10 round-0 rerank of buckets in LDS (or their plain
-// write-back), 11 round-0 bucket sorts through HBM, 12 round-0 bucket sorts in LDS.
+// write-back), 11 round-0 bucket sorts through HBM, 12 round-0 bucket sorts in LDS, 13 / 14 later
+// rounds' chunk sorts / chunk reranks in LDS.
 struct PhaseClock {
     unsigned long long t;
     unsigned long long* acc;
@@ -118,6 +119,7 @@ struct FwdShared {
     uint8_t sym[256];               // byte value -> code
     uint32_t wsum[W];
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
+    uint32_t chunk_bad;             // a doubling round's survivors cannot be cut into LDS-sized chunks of whole groups
     uint32_t tailrow[kMaxM0 + 1];   // final rows of the suffixes that reach the delimiter within m0 symbols
     uint32_t blk;
 };
@@ -1079,6 +1081,186 @@ __device__ __forceinline__ void ranks_by_search(const uint64_t* __restrict__ sor
     for (int u = 0; u < U; ++u) out[u] = lo[u];
 }
 
+// ---- doubling rounds inside LDS ---------------------------------------------------------------
+// The survivors of a round are sorted by group; a round only has to order each group by the
+// rank of the suffix h further on.  When the groups are small the survivor list is cut, at
+// group boundaries, into chunks that fit LDS, and every chunk is sorted (group, rank) and
+// reranked there -- the work of 4-7 radix passes through HBM plus a rerank sweep.
+
+// Cuts cur[0..m) (elements group << gshift | ..., groups ascending) into chunks of whole groups,
+// at most `cap` elements each: chunk k = [start[k], start[k+1]).  Returns the number of chunks,
+// or 0 when that is not possible (a group longer than the slack, or too many elements).
+template <int NT>
+__device__ __forceinline__ uint32_t cut_chunks(const uint64_t* __restrict__ cur, uint32_t m, int gshift,
+                                               uint32_t cap, uint32_t* __restrict__ start, FwdShared<NT>& sh) {
+    const uint32_t nominal = max(cap - cap / 6u, (m + (uint32_t)kMaxBuckets - 2u) / ((uint32_t)kMaxBuckets - 1u));
+    if (nominal > cap) return 0;  // workgroup-uniform
+    const uint32_t slack = cap - nominal;
+    const uint32_t nchunks = (m + nominal - 1u) / nominal;
+    if (threadIdx.x == 0) sh.chunk_bad = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k <= nchunks; k += NT) {
+        uint32_t sk = m;
+        if (k == 0) sk = 0;
+        else if (k < nchunks) {
+            const uint32_t p = k * nominal;
+            const uint64_t gk = cur[p] >> gshift;
+            uint32_t lo = p - min(p, slack), hi = p;  // first element of gk's group lies in [lo, p] ...
+            if ((cur[lo] >> gshift) == gk && lo > 0 && (cur[lo - 1] >> gshift) == gk) sh.chunk_bad = 1;  // ... or the group is too long
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((cur[mid] >> gshift) < gk) lo = mid + 1;
+                else hi = mid;
+            }
+            sk = lo;
+        }
+        start[k] = sk;
+    }
+    __syncthreads();
+    return sh.chunk_bad ? 0u : nchunks;
+}
+
+// Rerank of one chunk of a doubling round while it is sorted in LDS by (group, rank of the
+// suffix h further on): u.lsort[0..cnt), shifted left by `up` with the chunk's base key removed
+// (see lds_sort_bucket).  Equal keys stay one group; a suffix's rank moves up by the offset of
+// its run inside its old group; suffixes alone in their run are finished and store the byte
+// that precedes them at their row; the rest are appended to nxt with dense group ids.
+template <int NT>
+__device__ __forceinline__ void rerank_chunk(uint32_t cnt, uint64_t* __restrict__ nxt, uint32_t* __restrict__ rank,
+                                             const BlockIO& io, int ibits, int gshift, int up, FwdShared<NT>& sh,
+                                             uint32_t& m_tot, uint32_t& g_tot) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    const uint64_t* ls = sh.u.lsort;
+    Chunking ck;
+    ck.init(cnt, W);
+    const uint32_t lo = (uint32_t)w * ck.chunk;
+    const uint32_t hi = min(lo + ck.chunk, cnt);
+    const uint64_t lt = lanemask_lt(), le = lanemask_le();
+    const uint64_t imask = (1ull << ibits) - 1ull;
+    const int ks = ibits + up, gs = gshift + up;  // key = element >> ks, old group = element >> gs (64: one group)
+    auto group_of = [=](uint64_t y) { return gs < 64 ? y >> gs : 0ull; };
+    constexpr int kVecsPerWave = FwdShared<NT>::kSortCap / NT + 5;
+    uint64_t* flags = reinterpret_cast<uint64_t*>(sh.v.cw) + (size_t)w * 3 * kVecsPerWave;
+    static_assert(sizeof(sh.v.cw) >= (size_t)W * 3 * kVecsPerWave * sizeof(uint64_t), "room for three ballots per vector");
+    constexpr int U = NT <= 256 ? 4 : 2;  // vectors whose LDS and rank reads are issued together (a wide workgroup's wave has only 5 vectors)
+    const uint32_t kmax = cnt - 1u;
+    uint32_t cA = 0, cG = 0, lH = 0, lG = 0;
+    {
+        uint32_t v = 0;
+        for (uint32_t base = lo; base < hi; base += U * kWave, v += U) {
+            uint64_t y[U], yp[U], yn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = base + (uint32_t)(u * kWave + lane);
+                y[u] = ls[min(k, kmax)];
+                yp[u] = ls[min(k - 1u, kmax)];
+                yn[u] = ls[min(k + 1u, kmax)];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t vb = base + (uint32_t)(u * kWave);
+                if (vb < hi) {  // wave-uniform
+                    const uint32_t k = vb + lane;
+                    const bool valid = k < hi;
+                    const bool head = valid && (k == 0 || (yp[u] >> ks) != (y[u] >> ks));
+                    const bool tail = valid && (k + 1 == cnt || (yn[u] >> ks) != (y[u] >> ks));
+                    const bool ghead = valid && (k == 0 || group_of(yp[u]) != group_of(y[u]));
+                    const uint64_t H = __ballot(head), T = __ballot(tail), GH = __ballot(ghead);
+                    if (lane == 0) {
+                        flags[3 * (v + u)] = H;
+                        flags[3 * (v + u) + 1] = T;
+                        flags[3 * (v + u) + 2] = GH;
+                    }
+                    cA += __popcll(__ballot(valid) & ~(H & T));
+                    cG += __popcll(H & ~T);
+                    if (H) lH = vb + 63u - (uint32_t)__clzll(H);
+                    if (GH) lG = vb + 63u - (uint32_t)__clzll(GH);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        sh.cntA[w] = cA;
+        sh.cntG[w] = cG;
+        sh.lastH[w] = lH;
+        sh.lastG[w] = lG;
+    }
+    __syncthreads();
+    uint32_t baseA = m_tot, baseG = g_tot, carryH = 0, carryG = 0, totA = 0, totG = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t ca = sh.cntA[i], cg = sh.cntG[i];
+        if (i < w) {
+            baseA += ca;
+            baseG += cg;
+            carryH = max(carryH, sh.lastH[i]);
+            carryG = max(carryG, sh.lastG[i]);
+        }
+        totA += ca;
+        totG += cg;
+    }
+    {
+        uint32_t v = 0;
+        for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave, v += U) {
+            uint64_t y[U], Hs[U], Ts[U], Gs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                y[u] = ls[min(base0 + (uint32_t)(u * kWave + lane), kmax)];
+                Hs[u] = flags[3 * (v + u)];
+                Ts[u] = flags[3 * (v + u) + 1];
+                Gs[u] = flags[3 * (v + u) + 2];
+            }
+            // first the rank reads of the whole batch, then their uses
+            uint32_t idx[U], delta[U], rold[U];
+            bool single[U], act[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t base = base0 + (uint32_t)(u * kWave);
+                const uint32_t k = base + lane;
+                const bool valid = k < hi;  // false for the vectors past the chunk as well
+                const uint64_t H = Hs[u], G = Gs[u];
+                const uint64_t hm = H & le, gm = G & le;
+                const uint32_t khead = hm ? base + 63u - (uint32_t)__clzll(hm) : carryH;
+                const uint32_t kg = gm ? base + 63u - (uint32_t)__clzll(gm) : carryG;
+                if (base < hi) {
+                    if (H) carryH = base + 63u - (uint32_t)__clzll(H);
+                    if (G) carryG = base + 63u - (uint32_t)__clzll(G);
+                }
+                const bool head = (H >> lane) & 1u, tail = (Ts[u] >> lane) & 1u;
+                single[u] = valid && head && tail;
+                act[u] = valid && !single[u];
+                idx[u] = (uint32_t)((y[u] >> up) & imask);
+                delta[u] = valid ? khead - kg : 0u;
+                rold[u] = (delta[u] || single[u]) ? rank[idx[u]] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t base = base0 + (uint32_t)(u * kWave);
+                if (base < hi) {  // wave-uniform
+                    const uint64_t H = Hs[u], T = Ts[u];
+                    const uint64_t A = __ballot(act[u] || single[u]) & ~(H & T), NS = H & ~T;
+                    if (delta[u] || single[u]) {
+                        const uint32_t rn = rold[u] + delta[u];
+                        if (delta[u]) rank[idx[u]] = rn;
+                        if (single[u] && rn < io.n) io.out[rn] = idx[u] ? io.s[idx[u] - 1u] : (uint8_t)io.delim;
+                    }
+                    if (act[u]) {
+                        const uint32_t pos = baseA + __popcll(A & lt);
+                        const uint32_t gid = baseG + __popcll(NS & le) - 1u;
+                        nxt[pos] = ((uint64_t)gid << gshift) | idx[u];
+                    }
+                    baseA += __popcll(A);
+                    baseG += __popcll(NS);
+                }
+            }
+        }
+    }
+    m_tot += totA;
+    g_tot += totG;
+    __syncthreads();  // the counters, the ballots and the LDS chunk are free again
+}
+
 template <int NT>
 __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
                                               uint8_t* __restrict__ out, uint64_t* bufA, uint64_t* bufB,
@@ -1277,6 +1459,8 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         const bool first = h == (uint32_t)m0;  // ranks still are round-0 ranks
         DigitPlan plan;
         plan.init(rbits + gbits);
+        // small groups: the round runs chunk by chunk inside LDS (the bucket directory's slots hold the cuts)
+        const uint32_t nchunks = cut_chunks<NT>(alt, m, gshift, (uint32_t)FwdShared<NT>::kSortCap, dir.start, sh);
         zero_hist<NT>(sh, 0);
         __syncthreads();
         {
@@ -1332,13 +1516,32 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         }
         __syncthreads();
         pc.lap(4);
-        uint64_t* sorted = radix_sort<NT>(alt, cur, m, ibits, 0ull, plan, 0, sh, 0, &queue[1]);
-        pc.lap(5);
-        uint64_t* other = (sorted == alt) ? cur : alt;
-        uint32_t m2, G2;
-        bool unused;
-        rerank<NT, false>(sorted, other, rank, io, m, ibits, ibits, gshift, true, sh, m2, G2, unused);
-        pc.lap(6);
+        uint64_t* sorted;
+        uint64_t* other;
+        uint32_t m2 = 0, G2 = 0;
+        if (nchunks) {
+            for (uint32_t k = 0; k < nchunks; ++k) {
+                const uint32_t c0 = dir.start[k], cnt = dir.start[k + 1] - c0;
+                if (cnt == 0) continue;  // workgroup-uniform
+                const uint64_t gf = alt[c0] >> gshift, gl = alt[c0 + cnt - 1u] >> gshift;
+                int up;
+                uint64_t bsub;
+                lds_sort_bucket<NT>(alt + c0, cnt, ibits, gf << rbits, rbits + bit_length((uint32_t)(gl - gf)), sh, up,
+                                    bsub);
+                pc.lap(13);
+                rerank_chunk<NT>(cnt, cur, rank, io, ibits, gshift, up, sh, m2, G2);
+                pc.lap(14);
+            }
+            sorted = alt;  // its contents are spent; it is the scratch side of the next round
+            other = cur;   // the new survivor list
+        } else {
+            sorted = radix_sort<NT>(alt, cur, m, ibits, 0ull, plan, 0, sh, 0, &queue[1]);
+            pc.lap(5);
+            other = (sorted == alt) ? cur : alt;
+            bool unused;
+            rerank<NT, false>(sorted, other, rank, io, m, ibits, ibits, gshift, true, sh, m2, G2, unused);
+            pc.lap(6);
+        }
         pc.count(9, 1);
         if (!full) {
             if (m2 == 0) break;
