@@ -9,24 +9,31 @@
 // Algorithm (per block, n = len + 1 symbols including the appended delimiter)
 //   0. census: which byte values occur in the text -> dense order-preserving codes
 //      0..sigma-1, sbits = bits per code (the delimiter and the end get no code: round0_key).
-//   1. round 0: element i = (first m0 codes of suffix i, packed) << ibits | i, built by
-//      a rolling window over the input bytes; LSD radix sort of all n elements on the key.
-//      The first pass needs no stability, so the keys are generated straight into it and
-//      never stored unsorted.
-//   2. rerank: equal-key runs are groups; rank[i] = position of its group's first
-//      element (so a final rank IS the suffix-array position); suffixes alone in
-//      their group are finished and leave the working set (wave-ballot + prefix-
-//      count compaction); survivors get a dense group id g.
+//   1. round 0 sorts all n suffixes by their first m0 symbols.  Element i = key << (ibits+8) |
+//      preceding byte << ibits | i, the key built by a rolling window over the input bytes.
+//      A first sweep counts the keys per fine bin (top 13 key bits); the bins are grouped into
+//      buckets of contiguous key ranges and about equal population; a second sweep generates
+//      the elements again and partitions them into the buckets (one pass through HBM, runs of
+//      consecutive stores staged in LDS); every bucket is then loaded into LDS once and sorted
+//      there by the key bits its range leaves open (LSD, 4-bit digits, per-thread counters).
+//   2. rerank, on the bucket while it is still in LDS: equal-key runs are groups; rank[i] =
+//      row of its group's first element (so a final rank IS the suffix-array position);
+//      suffixes alone in their group are finished and leave the working set (wave-ballot +
+//      prefix-count compaction); survivors get a dense group id g.
 //   3. round r >= 1 (prefix length h doubles): element = g | rank[i+h]+1 | i for the
-//      survivors only; LSD radix sort on (g, rank[i+h]+1); rerank inside the old
-//      groups; repeat until no survivor is left.
+//      survivors only, ordered inside each old group by rank[i+h]: chunk by chunk inside LDS
+//      while the groups are small (cut_chunks / rerank_chunk), by LSD radix passes through HBM
+//      with a separate rerank sweep otherwise; repeat until no survivor is left.  While few
+//      suffixes survive round 0 their ranks are looked up by binary search in the sorted
+//      round-0 array instead of being written for everybody.
 //   4. output: a suffix that becomes alone in its group is finished; its rank is its row and
 //      it stores the byte that precedes it there (the delimiter for suffix 0 -- that row is
 //      the block's primary index).  Round-0 finishers carry that byte in their element and
 //      store it coalesced; later finishers fetch it from the text.
 //
-// Every array of a block lives in a per-workgroup slice of HBM scratch (two u64
-// element buffers and one u32 rank array); LDS holds the per-wave digit histograms.
+// Every array of a block lives in a per-workgroup slice of HBM scratch (two u64 element
+// buffers, one u32 rank array, a small bucket directory); LDS holds the staging tiles, the
+// bucket being sorted and the counters.
 #pragma once
 #include "bwt_device.hpp"
 
