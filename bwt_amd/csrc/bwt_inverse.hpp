@@ -195,6 +195,74 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
     }
 }
 
+// Collects bytes that arrive back to front and stores them below `end`: whole aligned 16-byte
+// groups where possible, single dwords and bytes at the two ragged ends, never a byte outside
+// [end - count, end).
+struct BackWriter {
+    uint8_t* addr;   // lowest address produced so far
+    uint8_t* daddr;  // where the completed dwords q0.. start
+    uint32_t acc, cnt, q0, q1, q2, q3, dcnt;
+    __device__ __forceinline__ void init(uint8_t* end) {
+        addr = daddr = end;
+        acc = cnt = q0 = q1 = q2 = q3 = dcnt = 0;
+    }
+    __device__ __forceinline__ void push(uint32_t ch) {
+        acc = (acc << 8) | ch;
+        ++cnt;
+        --addr;
+        if ((reinterpret_cast<uintptr_t>(addr) & 3u) == 0) {
+            if (cnt == 4) {
+                q3 = q2; q2 = q1; q1 = q0; q0 = acc;
+                daddr = addr;
+                ++dcnt;
+                if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
+                    if (dcnt == 4) {
+                        *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
+                    } else {
+                        uint32_t* d = reinterpret_cast<uint32_t*>(addr);
+                        d[0] = q0;
+                        if (dcnt > 1) d[1] = q1;
+                        if (dcnt > 2) d[2] = q2;
+                    }
+                    dcnt = 0;
+                }
+            } else {  // ragged upper end: the first dword is partial
+                for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
+            }
+            acc = 0;
+            cnt = 0;
+        }
+    }
+    // Four bytes at once: v's low byte goes to the lowest address.  Only at a dword boundary.
+    __device__ __forceinline__ void push_dword(uint32_t v) {
+        addr -= 4;
+        q3 = q2; q2 = q1; q1 = q0; q0 = v;
+        daddr = addr;
+        ++dcnt;
+        if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
+            if (dcnt == 4) {
+                *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
+            } else {
+                uint32_t* d = reinterpret_cast<uint32_t*>(addr);
+                d[0] = q0;
+                if (dcnt > 1) d[1] = q1;
+                if (dcnt > 2) d[2] = q2;
+            }
+            dcnt = 0;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
+        if (dcnt) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(daddr);
+            d[0] = q0;
+            if (dcnt > 1) d[1] = q1;
+            if (dcnt > 2) d[2] = q2;
+            if (dcnt > 3) d[3] = q3;
+        }
+    }
+};
+
 // ---- single chain (short blocks, blocks with several delimiters) -------------------------------
 // One chain per block, one lane per chain.  Every step is a single dependent load; the
 // loop is bounded by the block length, and a well-formed block ends it exactly there by
@@ -215,52 +283,18 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
     }
     const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
     uint8_t* const o = a.out + (uint64_t)b * a.block_size;
-    uint8_t* addr = o + len;  // lowest address written so far (exclusive end of what is left)
-    uint8_t* const floor_addr = o;
-    uint32_t acc = 0, cnt = 0;            // bytes of the dword in progress: acc's low byte is *addr
-    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, dcnt = 0;  // completed dwords, q0 lowest, at daddr + 4 j
-    uint8_t* daddr = addr;
+    BackWriter bw;
+    bw.init(o + len);
     row = T[row] & kRowMask;
     for (uint32_t step = 0; step < n; ++step) {
         const uint32_t wd = T[row];
         const uint32_t ch = wd >> 24;
-        if (ch == a.delim || addr == floor_addr) break;
+        if (ch == a.delim || bw.addr == o) break;
         row = wd & kRowMask;
-        acc = (acc << 8) | ch;
-        ++cnt;
-        --addr;
-        if ((reinterpret_cast<uintptr_t>(addr) & 3u) == 0) {
-            if (cnt == 4) {
-                q3 = q2; q2 = q1; q1 = q0; q0 = acc;
-                daddr = addr;
-                ++dcnt;
-                if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
-                    if (dcnt == 4) {
-                        *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
-                    } else {
-                        uint32_t* d = reinterpret_cast<uint32_t*>(addr);
-                        d[0] = q0;
-                        if (dcnt > 1) d[1] = q1;
-                        if (dcnt > 2) d[2] = q2;
-                    }
-                    dcnt = 0;
-                }
-            } else {  // unaligned end of the block's slot: first dword is partial
-                for (uint32_t j = 0; j < cnt; ++j) addr[j] = (uint8_t)(acc >> (8 * j));
-            }
-            acc = 0;
-            cnt = 0;
-        }
+        bw.push(ch);
     }
-    for (uint32_t j = 0; j < cnt; ++j) addr[j] = (uint8_t)(acc >> (8 * j));
-    if (dcnt) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(daddr);
-        d[0] = q0;
-        if (dcnt > 1) d[1] = q1;
-        if (dcnt > 2) d[2] = q2;
-        if (dcnt > 3) d[3] = q3;
-    }
-    a.lens[b] = (uint32_t)((o + len) - addr);
+    bw.flush();
+    a.lens[b] = (uint32_t)((o + len) - bw.addr);
 }
 
 // ---- segmented walk -------------------------------------------------------------------------
@@ -409,74 +443,6 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
         }
     }
 }
-
-// Collects bytes that arrive back to front and stores them below `end`: whole aligned 16-byte
-// groups where possible, single dwords and bytes at the two ragged ends, never a byte outside
-// [end - count, end).
-struct BackWriter {
-    uint8_t* addr;   // lowest address produced so far
-    uint8_t* daddr;  // where the completed dwords q0.. start
-    uint32_t acc, cnt, q0, q1, q2, q3, dcnt;
-    __device__ __forceinline__ void init(uint8_t* end) {
-        addr = daddr = end;
-        acc = cnt = q0 = q1 = q2 = q3 = dcnt = 0;
-    }
-    __device__ __forceinline__ void push(uint32_t ch) {
-        acc = (acc << 8) | ch;
-        ++cnt;
-        --addr;
-        if ((reinterpret_cast<uintptr_t>(addr) & 3u) == 0) {
-            if (cnt == 4) {
-                q3 = q2; q2 = q1; q1 = q0; q0 = acc;
-                daddr = addr;
-                ++dcnt;
-                if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
-                    if (dcnt == 4) {
-                        *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
-                    } else {
-                        uint32_t* d = reinterpret_cast<uint32_t*>(addr);
-                        d[0] = q0;
-                        if (dcnt > 1) d[1] = q1;
-                        if (dcnt > 2) d[2] = q2;
-                    }
-                    dcnt = 0;
-                }
-            } else {  // ragged upper end: the first dword is partial
-                for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
-            }
-            acc = 0;
-            cnt = 0;
-        }
-    }
-    // Four bytes at once: v's low byte goes to the lowest address.  Only at a dword boundary.
-    __device__ __forceinline__ void push_dword(uint32_t v) {
-        addr -= 4;
-        q3 = q2; q2 = q1; q1 = q0; q0 = v;
-        daddr = addr;
-        ++dcnt;
-        if ((reinterpret_cast<uintptr_t>(addr) & 15u) == 0) {
-            if (dcnt == 4) {
-                *reinterpret_cast<uint4*>(addr) = make_uint4(q0, q1, q2, q3);
-            } else {
-                uint32_t* d = reinterpret_cast<uint32_t*>(addr);
-                d[0] = q0;
-                if (dcnt > 1) d[1] = q1;
-                if (dcnt > 2) d[2] = q2;
-            }
-            dcnt = 0;
-        }
-    }
-    __device__ __forceinline__ void flush() {
-        for (uint32_t k = 0; k < cnt; ++k) addr[k] = (uint8_t)(acc >> (8 * k));
-        if (dcnt) {
-            uint32_t* d = reinterpret_cast<uint32_t*>(daddr);
-            d[0] = q0;
-            if (dcnt > 1) d[1] = q1;
-            if (dcnt > 2) d[2] = q2;
-            if (dcnt > 3) d[3] = q3;
-        }
-    }
-};
 
 // Moves every chained segment from its staging slot (and pool chunks) to its place: the bytes
 // were produced back to front, so byte t of the segment lands t + 1 bytes below its upper end.
