@@ -1285,7 +1285,24 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     // ---- 0. census and codes ------------------------------------------------
     if (tid < 256) sh.sym[tid] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < len; i += NT) sh.sym[s[i]] = 1;  // all writers store the same value
+    {   // all writers store the same value; 16 bytes per load once the address is aligned
+        const uint32_t head = min(len, (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(s) & 15u)) & 15u));
+        const uint32_t nvec = (len - head) / 16u;
+        const uint4* sv = reinterpret_cast<const uint4*>(s + head);
+        for (uint32_t i = tid; i < head; i += NT) sh.sym[s[i]] = 1;
+        for (uint32_t i0 = tid; i0 < nvec; i0 += 4 * NT) {
+            uint4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = sv[min(i0 + (uint32_t)(u * NT), nvec - 1u)];  // a repeated vector marks the same bytes again
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t wds[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sh.sym[(wds[k >> 2] >> (8 * (k & 3))) & 255u] = 1;
+            }
+        }
+        for (uint32_t i = head + 16u * nvec + tid; i < len; i += NT) sh.sym[s[i]] = 1;
+    }
     __syncthreads();
     const uint32_t present = tid < 256 ? sh.sym[tid] : 0;
     uint32_t sigma;  // distinct byte values in the text (the appended delimiter is not one of them)
