@@ -16,7 +16,7 @@
 //
 // The walk itself is a pointer chase of n dependent loads; one chain per block leaves the
 // memory system idle, so a well-formed block (exactly one delimiter) is cut into segments:
-// every kSplitStride-th row and the delimiter row are "splitters"; one lane per splitter
+// every 16th or 32nd row and the delimiter row are "splitters"; one lane per splitter
 // walks until it reaches the next splitter (whose own byte still belongs to it).
 //   bwt_inverse_walk_segments_kernel  every segment's length, the splitter it runs into and its
 //                                     bytes (into a 128-byte staging slot per segment; the few
@@ -42,10 +42,10 @@ namespace bwtgpu {
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr uint32_t kRowMask = 0x007FFFFFu;   // successor row (n <= 2^21 < 2^23)
 constexpr uint32_t kSplitFlag = 0x00800000u; // this row starts a segment
-constexpr uint32_t kSplitStride = 32;        // rows between regular splitters
+constexpr uint32_t kMinSplitShift = 4;       // rows between regular splitters: 16 or 32 (InvArgs::split_shift),
 constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain
 constexpr int kSegThreads = 256;             // workgroup size of the segment kernels
-constexpr uint32_t kSlot = 128;              // bytes of staging per segment; longer segments chain pool chunks of the same size
+                                             // staging slot per segment = 4 x that many bytes (InvArgs::slot)
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 constexpr uint32_t kModeMulti = 0, kModeSingle = 1, kModeNone = 2;
 
@@ -64,12 +64,14 @@ struct InvArgs {
     uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
     uint2* seg;           // nblocks * seg_cap: x = bytes the segment produces, y = id of the splitter it runs into
     uint32_t* seg_pos;    // nblocks * seg_cap: bytes between the segment's first byte and the text end
-    uint8_t* stage;       // nblocks * seg_cap * kSlot: the first kSlot bytes of every segment, in walk order
-    uint32_t* seg_ovf;    // nblocks * seg_cap: first pool chunk of a segment longer than kSlot (valid only then)
+    uint32_t split_shift; // log2 of the rows between regular splitters
+    uint32_t slot;        // bytes of staging per segment (power of two); longer segments chain pool chunks of the same size
+    uint8_t* stage;       // nblocks * seg_cap * slot: the first `slot` bytes of every segment, in walk order
+    uint32_t* seg_ovf;    // nblocks * seg_cap: first pool chunk of a segment longer than a slot (valid only then)
     uint32_t chunk_cap;   // pool chunks per block
     uint32_t* pool_used;  // per block: chunks handed out
     uint32_t* chunk_next; // nblocks * chunk_cap: the chunk that follows (valid only if the segment goes on)
-    uint8_t* pool;        // nblocks * chunk_cap * kSlot
+    uint8_t* pool;        // nblocks * chunk_cap * slot
     uint32_t* lens;       // per block: text length or BWTGPU_LEN_NO_DELIMITER
     uint32_t* queue;      // [0] next block index to hand out
 };
@@ -91,8 +93,8 @@ __device__ __forceinline__ uint32_t inv_block_len(const InvArgs& a, uint32_t b) 
 }
 
 // Regular splitters of a block of n rows: rows 0, stride, 2 stride, ...
-__device__ __host__ __forceinline__ uint32_t regular_splitters(uint32_t n) {
-    return (n + kSplitStride - 1u) / kSplitStride;
+__device__ __host__ __forceinline__ uint32_t regular_splitters(uint32_t n, uint32_t split_shift) {
+    return (n + (1u << split_shift) - 1u) >> split_shift;
 }
 
 template <int NT>
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
                     compiler_fence();  // every lane has read its offset before the leaders advance it
                     if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
                     compiler_fence();
-                    const uint32_t flag = (split && ((k & (kSplitStride - 1u)) == 0u || k == drow)) ? kSplitFlag : 0u;
+                    const uint32_t flag = (split && ((k & ((1u << a.split_shift) - 1u)) == 0u || k == drow)) ? kSplitFlag : 0u;
                     if (valid) T[k] = (b0 + rk) | flag | (c << 24);
                 }
             }
@@ -317,19 +319,19 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
     uint32_t b, j;
     if (!segment_of_lane(a, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
-    const uint32_t nreg = regular_splitters(n);
+    const uint32_t nreg = regular_splitters(n, a.split_shift);
     if (j > nreg) return;
     const uint32_t drow = a.drow[b];
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     a.seg_pos[sb + j] = kNoPos;
-    const uint32_t start = j < nreg ? j * kSplitStride : drow;
+    const uint32_t start = j < nreg ? (j << a.split_shift) : drow;
     if (j < nreg && start == drow) {
         a.seg[sb + j] = make_uint2(0u, j);
         return;
     }
     const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
-    uint8_t* buf = a.stage + (sb + j) * kSlot;
+    uint8_t* buf = a.stage + (sb + j) * a.slot;
     uint32_t prevc = 0;
     uint32_t row = T[start] & kRowMask;
     uint32_t t = 0;  // bytes the segment produces
@@ -343,13 +345,13 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
             stop = row;
             break;
         }
-        if (t && (t & (kSlot - 1u)) == 0u) {  // the slot (or chunk) is full: chain a pool chunk
+        if (t && (t & (a.slot - 1u)) == 0u) {  // the slot (or chunk) is full: chain a pool chunk
             const uint32_t c = atomicAdd(&a.pool_used[b], 1u);
-            if (c >= a.chunk_cap) break;  // cannot happen: the pool holds n / kSlot + 8 chunks
-            if (t == kSlot) a.seg_ovf[sb + j] = c;
+            if (c >= a.chunk_cap) break;  // cannot happen: the pool holds n / slot + 8 chunks
+            if (t == a.slot) a.seg_ovf[sb + j] = c;
             else a.chunk_next[pb + prevc] = c;
             prevc = c;
-            buf = a.pool + (pb + c) * kSlot;
+            buf = a.pool + (pb + c) * a.slot;
         }
         acc |= (wd >> 24) << (8u * (t & 3u));
         ++t;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
             acc = 0;
             if ((t & 15u) == 0u) {
                 const v4 val = {q0, q1, q2, q3};
-                __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t - 16u) & (kSlot - 1u))));
+                __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t - 16u) & (a.slot - 1u))));
             }
         }
         if (at_splitter) {  // a splitter's own byte belongs to the segment that reaches it
@@ -374,9 +376,9 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
         else if (have == 1) { val.x = q3; val.y = acc; }
         else if (have == 2) { val.x = q2; val.y = q3; val.z = acc; }
         else { val.x = q1; val.y = q2; val.z = q3; val.w = acc; }
-        __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t & ~15u) & (kSlot - 1u))));
+        __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t & ~15u) & (a.slot - 1u))));
     }
-    a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : stop / kSplitStride);
+    a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : (stop >> a.split_shift));
 }
 
 // Orders the segments of every split block: start at the delimiter row's segment, follow the
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
 // (short independent chains), one thread then orders the few hundred super nodes, and each
 // thread walks its chain again to hand out the positions.
 constexpr uint32_t kSuperStride = 32;
-constexpr uint32_t kMaxSupers = (BWTGPU_MAX_BLOCK_SIZE + 1u) / kSplitStride / kSuperStride + 2u;
+constexpr uint32_t kMaxSupers = ((BWTGPU_MAX_BLOCK_SIZE + 1u) >> kMinSplitShift) / kSuperStride + 2u;
 
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     const uint32_t b = blockIdx.x;
     if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
-    const uint32_t nreg = regular_splitters(n);
+    const uint32_t nreg = regular_splitters(n, a.split_shift);
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     const uint32_t last = (nreg + kSuperStride - 1u) / kSuperStride;  // super index of the delimiter's segment
     auto super_of = [&](uint32_t id) {  // super index of segment id, or kNoPos
@@ -444,13 +446,85 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     }
 }
 
+// The same ordering with the block's segment records held in LDS: following the links through
+// global memory is one random 64-byte transaction per segment and phase, in LDS it is a few
+// cycles.  For blocks of at most kStitchLdsSegs segments; one workgroup per CU.
+constexpr uint32_t kStitchLdsSegs = 16640;
+constexpr uint32_t kLdsSuperStride = 32;  // measured: 128 is slower (the longest of the chains sets the pace), 32 balances chains against the serial pass over super nodes
+constexpr uint32_t kStitchLdsSupers = kStitchLdsSegs / kLdsSuperStride + 2u;
+constexpr uint32_t kVisited = 0x80000000u;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
+    __shared__ uint2 s_seg[kStitchLdsSegs];
+    __shared__ uint32_t s_sum[kStitchLdsSupers], s_next[kStitchLdsSupers], s_pos[kStitchLdsSupers];
+    for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+        if (a.mode[b] != kModeMulti) continue;  // workgroup-uniform
+        const uint32_t n = inv_block_len(a, b);
+        const uint32_t nreg = regular_splitters(n, a.split_shift);
+        const uint64_t sb = (uint64_t)b * a.seg_cap;
+        const uint32_t last = (nreg + kLdsSuperStride - 1u) / kLdsSuperStride;
+        auto super_of = [&](uint32_t id) {
+            if (id >= nreg) return last;
+            return (id % kLdsSuperStride) == 0u ? id / kLdsSuperStride : kNoPos;
+        };
+        for (uint32_t i = threadIdx.x; i <= nreg; i += NT) s_seg[i] = a.seg[sb + i];
+        __syncthreads();
+        for (uint32_t u = threadIdx.x; u <= last; u += NT) {
+            uint32_t id = u == last ? nreg : u * kLdsSuperStride;
+            uint32_t sum = 0, nx = kNoPos;
+            for (uint32_t it = 0; it <= nreg; ++it) {
+                const uint2 sg = s_seg[id];
+                sum += sg.x;
+                nx = super_of(sg.y);
+                if (nx != kNoPos) break;
+                id = min(sg.y, nreg);
+            }
+            s_sum[u] = sum;
+            s_next[u] = nx;
+            s_pos[u] = kNoPos;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cur = last, total = 0;
+            for (uint32_t it = 0; it <= last; ++it) {
+                s_pos[cur] = total;
+                total += s_sum[cur];
+                const uint32_t nx = s_next[cur];
+                if (nx == last || nx == kNoPos) break;
+                cur = nx;
+            }
+            a.lens[b] = total < n ? total : n - 1;
+        }
+        __syncthreads();
+        for (uint32_t u = threadIdx.x; u <= last; u += NT) {
+            uint32_t pos = s_pos[u];
+            if (pos == kNoPos) continue;
+            uint32_t id = u == last ? nreg : u * kLdsSuperStride;
+            for (uint32_t it = 0; it <= nreg; ++it) {
+                const uint2 sg = s_seg[id];
+                s_seg[id] = make_uint2(sg.x | kVisited, pos);  // every segment lies on one super node's chain only
+                pos += sg.x;
+                if (super_of(sg.y) != kNoPos) break;
+                id = min(sg.y, nreg);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i <= nreg; i += NT) {
+            const uint2 sg = s_seg[i];
+            a.seg_pos[sb + i] = (sg.x & kVisited) ? sg.y : kNoPos;
+        }
+        __syncthreads();
+    }
+}
+
 // Moves every chained segment from its staging slot (and pool chunks) to its place: the bytes
 // were produced back to front, so byte t of the segment lands t + 1 bytes below its upper end.
 __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
     uint32_t b, j;
     if (!segment_of_lane(a, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
-    const uint32_t nreg = regular_splitters(n);
+    const uint32_t nreg = regular_splitters(n, a.split_shift);
     if (j > nreg) return;
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     const uint32_t pos = a.seg_pos[sb + j];
@@ -458,7 +532,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     const uint32_t len = a.seg[sb + j].x;
     if ((uint64_t)pos + len > (uint64_t)(n - 1)) return;  // never: the chain is at most n-1 bytes long
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
-    const uint8_t* src = a.stage + (sb + j) * kSlot;
+    const uint8_t* src = a.stage + (sb + j) * a.slot;
     uint32_t c = 0;
     BackWriter bw;
     bw.init(a.out + (uint64_t)b * a.block_size + (n - 1) - pos);
@@ -471,13 +545,13 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     const uint32_t last_group = (nd + 1u) >> 2;      // source dwords 0 .. nd+1 are consulted
     uint32_t prev = 0;
     for (uint32_t g = 0; g <= last_group; ++g) {
-        if (g && (g & (kSlot / 16u - 1u)) == 0u && 16u * g < len) {  // the next chunk of a long segment
-            c = g == kSlot / 16u ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
+        if (g && (g & ((a.slot / 16u) - 1u)) == 0u && 16u * g < len) {  // the next chunk of a long segment
+            c = g == (a.slot / 16u) ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
             if (c >= a.chunk_cap) break;  // never
-            src = a.pool + (pb + c) * kSlot;
+            src = a.pool + (pb + c) * a.slot;
         }
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + ((16u * g) & (kSlot - 1u)));
+        if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + ((16u * g) & (a.slot - 1u)));
         if (g == 0) {
             for (uint32_t k = 0; k < head; ++k) bw.push((v.x >> (8u * k)) & 255u);
         }

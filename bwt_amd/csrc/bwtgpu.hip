@@ -115,7 +115,7 @@ struct InvGeom {
     size_t nblocks;
     uint32_t tstride;
     uint32_t build_grid;
-    uint32_t seg_cap, seg_wgs, chunk_cap;
+    uint32_t seg_cap, seg_wgs, chunk_cap, split_shift, slot;
     bool split;  // blocks are long enough for the segmented walk
     size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
@@ -129,9 +129,16 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     const size_t max_wgs = (size_t)d.cus * (size_t)d.inv_wgs_per_cu;
     g.build_grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
     g.split = longest >= kMultiMinRows;
-    g.seg_cap = g.split ? regular_splitters((uint32_t)longest) + 1u : 1u;
+    // Splitter every 16 rows where the segment records of a block then still fit the LDS of the
+    // stitch kernel and the block is long enough to pay for twice the segments (measured: 256 KiB
+    // blocks gain, 64 KiB blocks lose); every 32 rows otherwise.
+    g.split_shift = kMinSplitShift;
+    if (longest < (size_t)192 << 10 || regular_splitters((uint32_t)longest, kMinSplitShift) + 1u > kStitchLdsSegs)
+        g.split_shift = kMinSplitShift + 1u;
+    g.slot = 4u << g.split_shift;
+    g.seg_cap = g.split ? regular_splitters((uint32_t)longest, g.split_shift) + 1u : 1u;
     g.seg_wgs = (g.seg_cap + kSegThreads - 1) / kSegThreads;
-    g.chunk_cap = g.split ? (uint32_t)(longest / kSlot) + 8u : 1u;
+    g.chunk_cap = g.split ? (uint32_t)(longest / g.slot) + 8u : 1u;
     size_t off = kHeaderBytes;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -145,8 +152,8 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.segpos_off = take(g.nblocks * g.seg_cap * 4);
     g.segovf_off = take(g.nblocks * g.seg_cap * 4);
     g.next_off = take(g.nblocks * (size_t)g.chunk_cap * 4);
-    g.stage_off = take(g.split ? g.nblocks * (size_t)g.seg_cap * kSlot : 0);
-    g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * kSlot : 0);
+    g.stage_off = take(g.split ? g.nblocks * (size_t)g.seg_cap * g.slot : 0);
+    g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * g.slot : 0);
     g.t_off = take((size_t)g.tstride * 4 * g.nblocks);
     g.bytes = off;
     return g;
@@ -446,6 +453,8 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.delim = delimiter;
     a.tstride = g.tstride;
     a.seg_cap = g.seg_cap;
+    a.split_shift = g.split_shift;
+    a.slot = g.slot;
     a.seg_wgs = g.seg_wgs;
     a.T = (uint32_t*)(ws + g.t_off);
     a.drow = (uint32_t*)(ws + g.drow_off);
@@ -470,7 +479,11 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
         hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
+        if (g.split_shift == kMinSplitShift)  // many segments per block: their records go through LDS (seg_cap <= kStitchLdsSegs then)
+            hipLaunchKernelGGL(bwt_inverse_stitch_lds_kernel<1024>, dim3((uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus)),
+                               dim3(1024), 0, s, a);
+        else
+            hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bwt_inverse_place_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
