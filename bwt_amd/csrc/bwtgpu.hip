@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bwt_forward.hpp"
+#include "bwt_forward_small.hpp"
 #include "bwt_inverse.hpp"
 #include "bwtgpu.h"
 
@@ -418,7 +419,11 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     a.ws = (uint8_t*)d_workspace + kHeaderBytes;
     a.ws_stride = g.stride;
     a.queue = (uint32_t*)d_workspace;
-    if (g.wide) hipLaunchKernelGGL(bwt_forward_kernel<kFwdWideThreads>, dim3(g.grid), dim3(kFwdWideThreads), 0, s, a);
+    if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
+        const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
+        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
+        hipLaunchKernelGGL(bwt_forward_small_kernel, dim3(grid), dim3(kSmallWaves * kWave), 0, s, a);
+    } else if (g.wide) hipLaunchKernelGGL(bwt_forward_kernel<kFwdWideThreads>, dim3(g.grid), dim3(kFwdWideThreads), 0, s, a);
     else hipLaunchKernelGGL(bwt_forward_kernel<kFwdThreads>, dim3(g.grid), dim3(kFwdThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
     return BWTGPU_OK;
