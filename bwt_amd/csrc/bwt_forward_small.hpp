@@ -4,7 +4,7 @@
 // dependent trips to HBM scratch on every block, which is what a 256 KiB block needs and far
 // too much for a 128-byte one (the reference CLI's default block size, src/bwt.cpp:239-261).
 // Here a block of up to kSmallCap symbols never leaves LDS: the 4 waves of a workgroup each
-// pull their own blocks from the batch queue and run plain prefix doubling
+// take every (number of waves)-th block of the batch and run plain prefix doubling
 // (src/bwt.cpp:50-99) wave-synchronously, without a single workgroup barrier:
 //   rank[i] = byte value + 1 (the appended delimiter by its byte value, 0 = past the end);
 //   round h: sort all suffixes by (rank[i], rank[i+h]) -- an in-place LSD radix sort of
@@ -38,11 +38,10 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void bwt_forward_small_kernel(F
     SmallWave& sh = shw[wave_id()];
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&a.queue[0], 1u);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= a.nblocks) break;
+    // blocks are dealt to the waves round robin: small blocks cost about the same each, and one
+    // queue counter for millions of blocks would serialise the whole launch on a single address
+    const uint32_t nwaves = gridDim.x * (uint32_t)kSmallWaves;
+    for (uint32_t b = blockIdx.x * (uint32_t)kSmallWaves + (uint32_t)wave_id(); b < a.nblocks; b += nwaves) {
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint64_t rem = a.total_len - off;
         const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;

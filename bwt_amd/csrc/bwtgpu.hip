@@ -13,6 +13,7 @@
 #include "bwt_forward.hpp"
 #include "bwt_forward_small.hpp"
 #include "bwt_inverse.hpp"
+#include "bwt_inverse_small.hpp"
 #include "bwtgpu.h"
 
 namespace {
@@ -474,6 +475,13 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.pool = ws + g.pool_off;
     a.lens = d_out_lens;
     a.queue = (uint32_t*)d_workspace;
+    if (block_size + 1 <= (size_t)kInvSmallCap) {  // small blocks: one wave per block, everything in LDS
+        const size_t wgs = (g.nblocks + kInvSmallWaves - 1) / kInvSmallWaves;
+        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 8));
+        hipLaunchKernelGGL(bwt_inverse_small_kernel, dim3(grid), dim3(kInvSmallWaves * kWave), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return BWTGPU_OK;
+    }
     hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
     const uint32_t per_block_grid = (uint32_t)((g.nblocks + kWave - 1) / kWave);
