@@ -1,6 +1,6 @@
 """Randomised differential test of the GPU path against the CPU oracle (run on a GPU box).
 
-usage: python tools/fuzz_gpu.py [trials] [seed]
+usage: python tools/fuzz_gpu.py [trials] [seed] [big]
 Covers: alphabet sizes incl. powers of two (delimiter above / below / inside the alphabet),
 runs, periodic text, repeated blocks, lengths around the internal size thresholds, batches.
 """
@@ -15,6 +15,7 @@ from bwt_amd import api  # noqa: E402
 
 orc = oracle.oracle()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+BIG_ONLY = len(sys.argv) > 3 and sys.argv[3] == "big"  # only long blocks and many-block batches
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 nrng = np.random.default_rng(rng.randrange(1 << 30))
 SIZES = [1, 2, 3, 7, 16, 17, 18, 63, 64, 65, 129, 255, 256, 257, 1000, 4095, 4096, 4097, 4863, 4864, 4865, 5119, 5120,
@@ -48,7 +49,7 @@ def make(n):
 fails = 0
 for t in range(trials):
     n = rng.choice(SIZES) if rng.random() < 0.7 else rng.randrange(1, 30000)
-    big = rng.random()
+    big = rng.random() * (0.1 if BIG_ONLY else 1.0)
     if big < 0.05:    # one long block: several buckets, the 1024-thread kernel
         n = rng.randrange(100000, 600000)
     elif big < 0.10:  # more blocks than compute units: the 256-thread batch kernel
