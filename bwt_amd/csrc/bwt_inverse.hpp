@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
     if (j > nreg) return;
     const uint32_t drow = a.drow[b];
     const uint64_t sb = (uint64_t)b * a.seg_cap;
-    a.seg_pos[sb + j] = kNoPos;
+    if (a.split_shift != kMinSplitShift) a.seg_pos[sb + j] = kNoPos;  // the LDS stitch writes every position itself
     const uint32_t start = j < nreg ? (j << a.split_shift) : drow;
     if (j < nreg && start == drow) {
         a.seg[sb + j] = make_uint2(0u, j);
