@@ -1,0 +1,411 @@
+// bwt_forward_grid.hpp -- forward BWT of a FEW LARGE blocks: the whole device sorts one batch.
+//
+// The batch kernel (bwt_forward.hpp) gives every block one workgroup, which fills the chip only
+// when there are hundreds of blocks.  A file of one or a few blocks -- the reference's own
+// benchmark runs the Canterbury files at block sizes up to 1 MiB, most of them a single block
+// (tests/performance.cpp:300-308) -- would leave all but a few compute units idle.  Here the
+// suffixes of ALL blocks of the batch form one array that every compute unit works on, one
+// kernel launch per step, the host reading one word per round (the number of suffixes still
+// tied) to size the next round and to know when to stop.
+//
+// Same algorithm as the reference's build_suffix_array (src/bwt.cpp:50-99), prefix doubling:
+//   row space   block b owns rows [b (block_size+1), ...) -- the very bytes of `out` it writes;
+//               a suffix is named by the row-space position g of its first symbol (the block's
+//               text followed by its delimiter), so one 32-bit id serves all blocks;
+//   round 0     key = (block, first m0 symbols as dense codes, 0 past the end); a device-wide
+//               LSD radix sort of (key, g) leaves every suffix at its row up to ties;
+//   rank        rank[g] = row of the first suffix with the same key (src/bwt.cpp:85-88 counts
+//               the same thing from 0 per block); a suffix whose key is unique is done: its
+//               output byte out[rank] = the byte before it, the delimiter for offset 0
+//               (src/bwt.cpp:102-123), is written at once;
+//   round h     only tied suffixes go on: key = (rank[g], rank[g+h] relative to the block + 1,
+//               0 past the end -- src/bwt.cpp:66-82 orders a missing second rank first), sorted
+//               again; ties of the new key share rank[g] + (offset of the tie inside the old
+//               tie); h doubles until nothing is tied.
+// The order is the reference's (unsigned bytes, shorter suffix first), so the bytes are the same.
+#pragma once
+#include "bwt_device.hpp"
+
+namespace bwtgpu {
+
+constexpr int kGridThreads = 256;
+constexpr int kGridWaves = kGridThreads / kWave;
+constexpr int kGridVecs = 8;                           // 64-element vectors per wave in one staged chunk
+constexpr int kGridChunk = kGridThreads * kGridVecs;   // elements a workgroup stages at a time
+constexpr int kGridDigitBits = 8;
+constexpr int kGridBins = 1 << kGridDigitBits;
+constexpr uint32_t kGridMaxTiles = 1024;               // workgroups of a sort or rank step
+constexpr int kGridScanThreads = 1024;
+constexpr int kGridRankVecs = 4;                       // consecutive elements per thread in the rank step
+constexpr int kGridRankChunk = kGridThreads * kGridRankVecs;
+
+struct GridArgs {
+    const uint8_t* in;    // block b reads in + b*block_size
+    uint8_t* out;         // block b writes out + b*(block_size+1)
+    uint64_t total_len;   // bytes of `in`
+    uint32_t block_size;
+    uint32_t nblocks;
+    uint32_t delim;
+    uint32_t rows;        // total_len + nblocks: suffixes of the whole batch
+    uint32_t* rank;       // rows words
+    const uint32_t* presence;  // 256-bit mask of the byte values in `in`
+    uint32_t* tile_hist;  // kGridBins * kGridMaxTiles words
+    uint32_t* tile_rec;   // 4 * kGridMaxTiles words
+    uint32_t* count;      // [0] suffixes still tied after the round
+};
+
+// Row-space position -> block, offset in the block's text (len = the delimiter's position).
+struct GridPos {
+    uint32_t b, off, len;
+};
+__device__ __forceinline__ GridPos grid_pos(const GridArgs& a, uint32_t g) {
+    GridPos p;
+    const uint32_t unit = a.block_size + 1u;
+    p.b = g / unit;
+    p.off = g - p.b * unit;
+    const uint64_t rem = a.total_len - (uint64_t)p.b * a.block_size;
+    p.len = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    return p;
+}
+
+// Exclusive running maximum of one value per thread over the workgroup (0 for thread 0);
+// `total` receives the workgroup maximum.  s_w needs NT/64 words.  Contains two barriers.
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_max(uint32_t v, uint32_t* s_w, uint32_t& total) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x = max(x, y);
+    }
+    if (lane == kWave - 1) s_w[w] = x;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t t = s_w[i];
+        if (i < w) pre = max(pre, t);
+        tot = max(tot, t);
+    }
+    __syncthreads();
+    total = tot;
+    const uint32_t below = __shfl_up(x, 1);  // inclusive maximum of the lanes below mine
+    return max(pre, lane ? below : 0u);
+}
+
+// ---- round 0 keys ---------------------------------------------------------------------------
+// key[g] = block << (m0*sbits) | codes of the m0 symbols from g on, id[g] = g.  Codes are dense:
+// 1 + the number of smaller byte values that occur in the batch (the delimiter counted among
+// them), which keeps the byte order and leaves 0 for "past the end".
+__global__ __launch_bounds__(kGridThreads) void grid_keys0_kernel(GridArgs a, uint64_t* __restrict__ key,
+                                                                  uint32_t* __restrict__ id, uint32_t m0,
+                                                                  uint32_t sbits) {
+    __shared__ uint16_t s_code[256];
+    {
+        const uint32_t c = threadIdx.x;
+        uint32_t below = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; ++w) {
+            uint32_t m = a.presence[w];
+            if ((a.delim >> 5) == w) m |= 1u << (a.delim & 31u);
+            if (w < (c >> 5)) below += __popc(m);
+            else if (w == (c >> 5)) below += __popc(m & ((1u << (c & 31u)) - 1u));
+        }
+        s_code[c] = (uint16_t)(below + 1u);
+    }
+    __syncthreads();
+    const uint32_t dcode = s_code[a.delim];
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    for (uint32_t g = blockIdx.x * kGridThreads + threadIdx.x; g < a.rows; g += nthreads) {
+        const GridPos p = grid_pos(a, g);
+        const uint8_t* __restrict__ s = a.in + (uint64_t)p.b * a.block_size;
+        uint64_t k = p.b;
+        for (uint32_t i = 0; i < m0; ++i) {
+            const uint32_t q = p.off + i;
+            const uint32_t c = q < p.len ? s_code[s[q]] : q == p.len ? dcode : 0u;
+            k = (k << sbits) | c;
+        }
+        key[g] = k;
+        id[g] = g;
+    }
+}
+
+// ---- later keys --------------------------------------------------------------------------------
+// key[j] = rank[g] << b2 | (rank[g+h] - first row of the block + 1, or 0 past the block's end).
+__global__ __launch_bounds__(kGridThreads) void grid_keys_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                 uint32_t m, uint64_t h, uint32_t b2,
+                                                                 uint64_t* __restrict__ key) {
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+        const uint32_t g = id[j];
+        const GridPos p = grid_pos(a, g);
+        const uint32_t base = g - p.off;
+        uint32_t r2 = 0;
+        if ((uint64_t)p.off + h <= (uint64_t)p.len) r2 = a.rank[g + (uint32_t)h] - base + 1u;
+        key[j] = ((uint64_t)a.rank[g] << b2) | r2;
+    }
+}
+
+// ---- device-wide LSD radix pass: count, scan, scatter ------------------------------------------
+// Tile t = elements [t*tile, (t+1)*tile); tile_hist[bin * ntiles + t] = its count of digit `bin`.
+__global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t* __restrict__ key, uint32_t m,
+                                                                 uint32_t tile, uint32_t ntiles, uint32_t shift,
+                                                                 uint32_t mask, uint32_t* __restrict__ tile_hist) {
+    __shared__ uint32_t s_h[kGridBins];
+    const uint32_t t = blockIdx.x;
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kGridThreads)
+        atomicAdd(&s_h[(uint32_t)(key[i] >> shift) & mask], 1u);
+    __syncthreads();
+    tile_hist[threadIdx.x * ntiles + t] = s_h[threadIdx.x];
+}
+
+// In-place exclusive prefix sum of v[0..len) by one workgroup.
+__global__ __launch_bounds__(kGridScanThreads) void grid_scan_kernel(uint32_t* __restrict__ v, uint32_t len) {
+    __shared__ uint32_t s_w[kGridScanThreads / kWave];
+    const uint32_t per = (len + kGridScanThreads - 1u) / kGridScanThreads;
+    const uint32_t lo = min(threadIdx.x * per, len), hi = min(lo + per, len);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += v[i];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<kGridScanThreads>(sum, s_w, total);
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t x = v[i];
+        v[i] = run;
+        run += x;
+    }
+}
+
+// Stable scatter of tile t by the digit: tile_hist (scanned) holds where the tile's elements of
+// every digit start.  A chunk of kGridChunk elements is ranked (wave ballot match + per-wave
+// counters, waves and vectors in element order), gathered by digit in LDS, and written out in
+// runs of equal digit.
+__global__ __launch_bounds__(kGridThreads) void grid_scatter_kernel(const uint64_t* __restrict__ key_in,
+                                                                    const uint32_t* __restrict__ id_in,
+                                                                    uint64_t* __restrict__ key_out,
+                                                                    uint32_t* __restrict__ id_out, uint32_t m,
+                                                                    uint32_t tile, uint32_t ntiles, uint32_t shift,
+                                                                    uint32_t mask,
+                                                                    const uint32_t* __restrict__ tile_hist) {
+    __shared__ uint32_t s_cursor[kGridBins];             // where the next element of each digit goes
+    __shared__ uint32_t s_wcnt[kGridWaves][kGridBins];   // per wave: count so far, then chunk-local start
+    __shared__ uint32_t s_gbase[kGridBins];              // output position minus chunk-local position
+    __shared__ uint32_t s_wsum[kGridWaves];
+    __shared__ uint64_t s_key[kGridChunk];
+    __shared__ uint32_t s_id[kGridChunk];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t t = blockIdx.x;
+    s_cursor[tid] = tile_hist[(uint32_t)tid * ntiles + t];
+    const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
+    for (uint32_t base = lo; base < hi; base += kGridChunk) {
+        const uint32_t cnt = min(hi - base, (uint32_t)kGridChunk);
+#pragma unroll
+        for (int i = 0; i < kGridWaves; ++i) s_wcnt[i][tid] = 0;
+        __syncthreads();
+        uint64_t k[kGridVecs];
+        uint32_t ids[kGridVecs], lr[kGridVecs];
+#pragma unroll
+        for (int v = 0; v < kGridVecs; ++v) {
+            const uint32_t e = (uint32_t)((w * kGridVecs + v) * kWave + lane);
+            const bool valid = e < cnt;
+            k[v] = valid ? key_in[base + e] : 0ull;
+            ids[v] = valid ? id_in[base + e] : 0u;
+        }
+#pragma unroll
+        for (int v = 0; v < kGridVecs; ++v) {
+            const uint32_t e = (uint32_t)((w * kGridVecs + v) * kWave + lane);
+            const bool valid = e < cnt;
+            const uint32_t d = (uint32_t)(k[v] >> shift) & mask;
+            const uint64_t peers = match_digit<kGridDigitBits>(d, valid);
+            const uint32_t rk = __popcll(peers & lt);
+            const uint32_t c0 = s_wcnt[w][d];
+            compiler_fence();  // every lane has read the count before the leaders advance it
+            if (valid && rk == 0) s_wcnt[w][d] = c0 + (uint32_t)__popcll(peers);
+            compiler_fence();
+            lr[v] = c0 + rk;
+        }
+        __syncthreads();
+        {   // thread d: chunk-local start of digit d, per wave, and the digit's place in the output
+            uint32_t c[kGridWaves], tot = 0;
+#pragma unroll
+            for (int i = 0; i < kGridWaves; ++i) {
+                c[i] = s_wcnt[i][tid];
+                tot += c[i];
+            }
+            uint32_t total;
+            const uint32_t start = block_exclusive_scan<kGridThreads>(tot, s_wsum, total);
+            uint32_t run = start;
+#pragma unroll
+            for (int i = 0; i < kGridWaves; ++i) {
+                s_wcnt[i][tid] = run;
+                run += c[i];
+            }
+            s_gbase[tid] = s_cursor[tid] - start;
+            s_cursor[tid] += tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < kGridVecs; ++v) {
+            const uint32_t e = (uint32_t)((w * kGridVecs + v) * kWave + lane);
+            if (e < cnt) {
+                const uint32_t d = (uint32_t)(k[v] >> shift) & mask;
+                const uint32_t p = s_wcnt[w][d] + lr[v];
+                s_key[p] = k[v];
+                s_id[p] = ids[v];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += kGridThreads) {
+            const uint64_t kk = s_key[i];
+            const uint32_t pos = s_gbase[(uint32_t)(kk >> shift) & mask] + i;
+            key_out[pos] = kk;
+            id_out[pos] = s_id[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- ranks from the sorted keys -----------------------------------------------------------------
+// Over the sorted list, position j starts a key run if key[j] != key[j-1] and an r1 run if the
+// old rank (key >> b2; the same for all in round 0) changes.  With s2 / s1 = start of j's key /
+// r1 run, the new rank is r1 + (s2 - s1) -- in round 0 simply s2, the list being all rows in
+// order.  A key run of length 1 is a finished suffix.  Three steps: per tile the last run starts
+// and the number of unfinished suffixes (reduce), their running values over the tiles (scan),
+// and the pass that writes ranks, output bytes and the list of unfinished suffixes (apply).
+struct GridFlags {
+    bool khead, rhead, single;
+};
+__device__ __forceinline__ GridFlags grid_flags(uint64_t prev, uint64_t cur, uint64_t next, uint32_t j, uint32_t m,
+                                                uint32_t b2, bool round0) {
+    GridFlags f;
+    f.khead = j == 0 || cur != prev;
+    f.rhead = j == 0 || (!round0 && (cur >> b2) != (prev >> b2));
+    f.single = f.khead && (j + 1u == m || next != cur);
+    return f;
+}
+
+__global__ __launch_bounds__(kGridThreads) void grid_rank_reduce_kernel(const uint64_t* __restrict__ key, uint32_t m,
+                                                                        uint32_t tile, uint32_t b2, int round0,
+                                                                        uint32_t* __restrict__ tile_rec) {
+    __shared__ uint32_t s_k[kGridWaves], s_r[kGridWaves], s_n[kGridWaves];
+    const uint32_t t = blockIdx.x;
+    const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
+    uint32_t lastk = 0, lastr = 0, tied = 0;  // run starts as position + 1, 0 = none
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kGridThreads) {
+        const uint64_t cur = key[j];
+        const uint64_t prev = j ? key[j - 1u] : 0ull, next = j + 1u < m ? key[j + 1u] : 0ull;
+        const GridFlags f = grid_flags(prev, cur, next, j, m, b2, round0 != 0);
+        if (f.khead) lastk = j + 1u;
+        if (f.rhead) lastr = j + 1u;
+        tied += f.single ? 0u : 1u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lastk = max(lastk, (uint32_t)__shfl_xor(lastk, o));
+        lastr = max(lastr, (uint32_t)__shfl_xor(lastr, o));
+        tied += __shfl_xor(tied, o);
+    }
+    if (lane_id() == 0) {
+        s_k[wave_id()] = lastk;
+        s_r[wave_id()] = lastr;
+        s_n[wave_id()] = tied;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t k = 0, r = 0, n = 0;
+#pragma unroll
+        for (int i = 0; i < kGridWaves; ++i) {
+            k = max(k, s_k[i]);
+            r = max(r, s_r[i]);
+            n += s_n[i];
+        }
+        tile_rec[4u * t + 0u] = k;
+        tile_rec[4u * t + 1u] = r;
+        tile_rec[4u * t + 2u] = n;
+    }
+}
+
+// One workgroup, one thread per tile: what every tile inherits from the tiles before it.
+__global__ __launch_bounds__(kGridScanThreads) void grid_rank_scan_kernel(uint32_t* __restrict__ tile_rec,
+                                                                          uint32_t ntiles,
+                                                                          uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_w[kGridScanThreads / kWave];
+    const uint32_t t = threadIdx.x;
+    const bool have = t < ntiles;
+    const uint32_t k = have ? tile_rec[4u * t + 0u] : 0u, r = have ? tile_rec[4u * t + 1u] : 0u,
+                   n = have ? tile_rec[4u * t + 2u] : 0u;
+    uint32_t tk, tr, tn;
+    const uint32_t pk = block_exclusive_max<kGridScanThreads>(k, s_w, tk);
+    const uint32_t pr = block_exclusive_max<kGridScanThreads>(r, s_w, tr);
+    const uint32_t pn = block_exclusive_scan<kGridScanThreads>(n, s_w, tn);
+    if (have) {
+        tile_rec[4u * t + 0u] = pk;
+        tile_rec[4u * t + 1u] = pr;
+        tile_rec[4u * t + 2u] = pn;
+    }
+    if (t == 0) count[0] = tn;
+}
+
+__global__ __launch_bounds__(kGridThreads) void grid_rank_apply_kernel(GridArgs a, const uint64_t* __restrict__ key,
+                                                                       const uint32_t* __restrict__ id, uint32_t m,
+                                                                       uint32_t tile, uint32_t b2, int round0,
+                                                                       const uint32_t* __restrict__ tile_rec,
+                                                                       uint32_t* __restrict__ id_out) {
+    __shared__ uint32_t s_w[kGridWaves];
+    const uint32_t t = blockIdx.x;
+    const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
+    uint32_t cark = tile_rec[4u * t + 0u], carr = tile_rec[4u * t + 1u], carn = tile_rec[4u * t + 2u];
+    for (uint32_t base = lo; base < hi; base += kGridRankChunk) {
+        const uint32_t j0 = base + threadIdx.x * kGridRankVecs;
+        uint64_t k[kGridRankVecs + 2];  // key[j0-1 .. j0+kGridRankVecs]
+#pragma unroll
+        for (int i = 0; i < kGridRankVecs + 2; ++i) {
+            const uint32_t j = j0 + (uint32_t)i - 1u;
+            k[i] = (j0 + (uint32_t)i >= 1u && j < m) ? key[j] : 0ull;
+        }
+        GridFlags f[kGridRankVecs];
+        uint32_t lastk = 0, lastr = 0, tied = 0;
+#pragma unroll
+        for (int i = 0; i < kGridRankVecs; ++i) {
+            const uint32_t j = j0 + (uint32_t)i;
+            f[i] = grid_flags(k[i], k[i + 1], k[i + 2], j, m, b2, round0 != 0);
+            if (j < hi) {
+                if (f[i].khead) lastk = j + 1u;
+                if (f[i].rhead) lastr = j + 1u;
+                tied += f[i].single ? 0u : 1u;
+            }
+        }
+        uint32_t tk, tr, tn;
+        uint32_t curk = max(cark, block_exclusive_max<kGridThreads>(lastk, s_w, tk));
+        uint32_t curr = max(carr, block_exclusive_max<kGridThreads>(lastr, s_w, tr));
+        uint32_t slot = carn + block_exclusive_scan<kGridThreads>(tied, s_w, tn);
+#pragma unroll
+        for (int i = 0; i < kGridRankVecs; ++i) {
+            const uint32_t j = j0 + (uint32_t)i;
+            if (j < hi) {
+                if (f[i].khead) curk = j + 1u;
+                if (f[i].rhead) curr = j + 1u;
+                const uint32_t r1 = round0 ? 0u : (uint32_t)(k[i + 1] >> b2);
+                const uint32_t nr = r1 + (curk - curr);  // both are position + 1
+                const uint32_t g = id[j];
+                a.rank[g] = nr;
+                if (f[i].single) {
+                    const GridPos p = grid_pos(a, g);
+                    a.out[nr] = p.off ? a.in[(uint64_t)p.b * a.block_size + p.off - 1u] : (uint8_t)a.delim;
+                } else {
+                    id_out[slot++] = g;
+                }
+            }
+        }
+        cark = max(cark, tk);
+        carr = max(carr, tr);
+        carn += tn;
+    }
+}
+
+}  // namespace bwtgpu

@@ -6,11 +6,13 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 #include "bwt_forward.hpp"
+#include "bwt_forward_grid.hpp"
 #include "bwt_forward_small.hpp"
 #include "bwt_inverse.hpp"
 #include "bwt_inverse_small.hpp"
@@ -95,8 +97,62 @@ struct FwdGeom {
     size_t stride;   // bytes of scratch per workgroup
     uint32_t grid;
     bool wide;       // few blocks: 1024-thread workgroups, one per CU
+    bool grid_path;  // few large blocks: all compute units work on the one batch
     size_t bytes;    // whole workspace
 };
+
+// ---- few large blocks: the device-wide path (bwt_forward_grid.hpp) --------------------------
+// Measured on MI355X: the device-wide path takes about 0.25 ms plus 1.3 us per KiB of the whole
+// batch (random bytes; text about three times that), the batch kernel 8.5 us per KiB of ONE block
+// (text: 25 us) as long as every block has a workgroup of its own -- so the former wins while the
+// batch is shorter than about six blocks, and for short blocks only with fewer still.
+constexpr size_t kGridMaxBlocks = 6;
+constexpr size_t kGridShortBlock = (size_t)128 << 10;  // blocks below this: at most kGridMaxShortBlocks
+constexpr size_t kGridMaxShortBlocks = 3;
+constexpr size_t kGridMinRows = 24576;       // below this the launches of the device-wide path cost more than they save
+constexpr size_t kGridMaxRows = (size_t)1 << 31;
+
+// BWTGPU_FORWARD_PATH=grid|block overrides the choice between the two forward paths (tests
+// run every case through both); anything else, or unset, leaves it to the batch shape.
+int forced_forward_path() {
+    const char* e = std::getenv("BWTGPU_FORWARD_PATH");
+    if (!e) return 0;
+    if (!strcmp(e, "grid")) return 1;
+    if (!strcmp(e, "block")) return 2;
+    return 0;
+}
+
+struct GridGeom {
+    size_t rows;
+    size_t presence_off, count_off, hist_off, rec_off, rank_off, key_off[2], id_off[2], bytes;
+};
+
+GridGeom grid_geom(size_t total_len, size_t block_size) {
+    GridGeom g;
+    g.rows = total_len + (total_len + block_size - 1) / block_size;
+    size_t off = kHeaderBytes;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = round_up(off + bytes, 256);
+        return at;
+    };
+    g.presence_off = take(32);
+    g.count_off = take(4);
+    g.hist_off = take((size_t)kGridBins * kGridMaxTiles * 4);
+    g.rec_off = take((size_t)kGridMaxTiles * 16);
+    g.rank_off = take(g.rows * 4);
+    for (int i = 0; i < 2; ++i) g.key_off[i] = take(g.rows * 8);
+    for (int i = 0; i < 2; ++i) g.id_off[i] = take(g.rows * 4);
+    g.bytes = off;
+    return g;
+}
+
+size_t grid_block_limit(size_t block_size) { return block_size < kGridShortBlock ? kGridMaxShortBlocks : kGridMaxBlocks; }
+
+bool grid_shape(size_t total_len, size_t block_size) {
+    const size_t nblocks = (total_len + block_size - 1) / block_size;
+    return nblocks <= grid_block_limit(block_size) && total_len + nblocks >= kGridMinRows;
+}
 
 FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     FwdGeom g;
@@ -110,6 +166,14 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     // whole cost: give every block a 1024-thread workgroup instead.
     g.wide = g.nblocks <= (size_t)d.cus && longest >= kWideMinBlock;
     g.bytes = kHeaderBytes + g.stride * g.grid;
+    // The device-wide path serves the batch itself or, when a caller sizes its workspace for a
+    // full slab and then submits a shorter one, any prefix of it.
+    const int forced = forced_forward_path();
+    g.grid_path = total_len + g.nblocks <= kGridMaxRows && forced != 2 && (forced == 1 || grid_shape(total_len, block_size));
+    if (forced != 2) {
+        const size_t most = forced == 1 ? total_len : std::min(total_len, grid_block_limit(block_size) * block_size);
+        if (forced == 1 || grid_shape(most, block_size)) g.bytes = std::max(g.bytes, grid_geom(most, block_size).bytes);
+    }
     return g;
 }
 
@@ -271,6 +335,110 @@ int ensure_device(int device) {
     return BWTGPU_OK;
 }
 
+// ---- forward, device-wide path: one batch of few large blocks --------------------------------
+// Pinned words the calling thread reads device results through (byte presence, suffixes left).
+uint32_t* pinned_words() {
+    thread_local uint32_t* p = nullptr;
+    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) p = nullptr;
+    return p;
+}
+
+uint32_t grid_tile(uint32_t m) {
+    const size_t per = ((size_t)m + kGridMaxTiles - 1) / kGridMaxTiles;
+    return (uint32_t)round_up(std::max<size_t>(per, 1), kGridChunk);
+}
+
+int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
+                 uint8_t* d_out, void* d_workspace, hipStream_t s) {
+    const GridGeom g = grid_geom(total_len, block_size);
+    uint8_t* ws = (uint8_t*)d_workspace;
+    uint32_t* host = pinned_words();
+    if (!host) return fail(BWTGPU_ERR_HIP, "hipHostMalloc of the result words failed");
+    GridArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.total_len = total_len;
+    a.block_size = (uint32_t)block_size;
+    a.nblocks = (uint32_t)((total_len + block_size - 1) / block_size);
+    a.delim = delimiter;
+    a.rows = (uint32_t)g.rows;
+    a.rank = (uint32_t*)(ws + g.rank_off);
+    a.presence = (uint32_t*)(ws + g.presence_off);
+    a.tile_hist = (uint32_t*)(ws + g.hist_off);
+    a.tile_rec = (uint32_t*)(ws + g.rec_off);
+    a.count = (uint32_t*)(ws + g.count_off);
+    uint64_t* key[2] = {(uint64_t*)(ws + g.key_off[0]), (uint64_t*)(ws + g.key_off[1])};
+    uint32_t* id[2] = {(uint32_t*)(ws + g.id_off[0]), (uint32_t*)(ws + g.id_off[1])};
+
+    // byte values in the batch -> symbol width and how many symbols the first key holds
+    HIP_TRY(hipMemsetAsync(ws + g.presence_off, 0, 32, s));
+    hipLaunchKernelGGL(presence_kernel, dim3(stream_grid(d, total_len, 256 * 64)), dim3(256), 0, s, d_in, total_len,
+                       (uint32_t*)(ws + g.presence_off));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, ws + g.presence_off, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    host[delimiter >> 5] |= 1u << (delimiter & 31);
+    uint32_t sigma = 0;
+    for (int i = 0; i < 8; ++i) sigma += (uint32_t)__builtin_popcount(host[i]);
+    const int sbits = bit_length(sigma);                       // codes 1 .. sigma
+    const int bbits = bit_length(a.nblocks - 1u);
+    const size_t longest = std::min(total_len, block_size) + 1;  // symbols of the longest block, delimiter included
+    int m0 = std::max(1, (40 - bbits) / sbits);                // five 8-bit passes
+    m0 = (int)std::min<size_t>((size_t)m0, longest);
+    const int b1 = bit_length(a.rows - 1u), b2 = bit_length((uint32_t)longest);
+
+    int cur = 0;  // key[cur] / id[cur] hold the list the next step reads
+    auto sort = [&](uint32_t m, int bits) -> int {
+        const uint32_t tile = grid_tile(m), ntiles = (m + tile - 1) / tile;
+        for (int shift = 0; shift < bits; shift += kGridDigitBits) {
+            const uint32_t mask = (1u << std::min(kGridDigitBits, bits - shift)) - 1u;
+            hipLaunchKernelGGL(grid_hist_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, key[cur], m, tile, ntiles,
+                               (uint32_t)shift, mask, a.tile_hist);
+            hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(kGridScanThreads), 0, s, a.tile_hist,
+                               (uint32_t)kGridBins * ntiles);
+            hipLaunchKernelGGL(grid_scatter_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, key[cur], id[cur],
+                               key[cur ^ 1], id[cur ^ 1], m, tile, ntiles, (uint32_t)shift, mask, a.tile_hist);
+            HIP_TRY(hipGetLastError());
+            cur ^= 1;
+        }
+        return BWTGPU_OK;
+    };
+    // ranks of the sorted list in key[cur] / id[cur]; the suffixes still tied go to id[cur ^ 1]
+    auto rerank = [&](uint32_t m, bool round0, uint32_t* left) -> int {
+        const uint32_t tile = grid_tile(m), ntiles = (m + tile - 1) / tile;
+        hipLaunchKernelGGL(grid_rank_reduce_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, key[cur], m, tile,
+                           (uint32_t)b2, round0 ? 1 : 0, a.tile_rec);
+        hipLaunchKernelGGL(grid_rank_scan_kernel, dim3(1), dim3(kGridScanThreads), 0, s, a.tile_rec, ntiles, a.count);
+        hipLaunchKernelGGL(grid_rank_apply_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, a, key[cur], id[cur], m,
+                           tile, (uint32_t)b2, round0 ? 1 : 0, a.tile_rec, id[cur ^ 1]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host, a.count, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *left = host[0];
+        cur ^= 1;  // the tied suffixes are the next list
+        return BWTGPU_OK;
+    };
+
+    int rc;
+    uint32_t m = a.rows;
+    hipLaunchKernelGGL(grid_keys0_kernel, dim3(stream_grid(d, m, kGridThreads * 4)), dim3(kGridThreads), 0, s, a,
+                       key[cur], id[cur], (uint32_t)m0, (uint32_t)sbits);
+    HIP_TRY(hipGetLastError());
+    if ((rc = sort(m, bbits + m0 * sbits))) return rc;
+    if ((rc = rerank(m, true, &m))) return rc;
+    uint64_t h = (uint64_t)m0;
+    for (int round = 0; m; ++round) {
+        if (round >= 64 || m > a.rows) return fail(BWTGPU_ERR_INTERNAL, "device-wide suffix sort did not converge");
+        hipLaunchKernelGGL(grid_keys_kernel, dim3(stream_grid(d, m, kGridThreads * 4)), dim3(kGridThreads), 0, s, a,
+                           id[cur], m, h, (uint32_t)b2, key[cur]);
+        HIP_TRY(hipGetLastError());
+        if ((rc = sort(m, b1 + b2))) return rc;
+        if ((rc = rerank(m, false, &m))) return rc;
+        h *= 2;
+    }
+    return BWTGPU_OK;
+}
+
 // ---- slab pipeline ------------------------------------------------------------
 struct PipeSlot {
     uint8_t* h_in = nullptr;
@@ -420,6 +588,7 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     a.ws = (uint8_t*)d_workspace + kHeaderBytes;
     a.ws_stride = g.stride;
     a.queue = (uint32_t*)d_workspace;
+    if (g.grid_path) return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
     if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
         const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));

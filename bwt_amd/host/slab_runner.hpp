@@ -42,49 +42,70 @@ inline size_t slab_blocks_for(size_t unit_bytes, size_t file_bytes) {
     if (blocks * unit_bytes > kMaxBytes) blocks = kMaxBytes / unit_bytes;
     if (blocks == 0) blocks = 1;
     if (file_bytes) {
-        const size_t need = (file_bytes + unit_bytes - 1) / unit_bytes;
-        if (need < blocks) blocks = need ? need : 1;
+        size_t need = (file_bytes + unit_bytes - 1) / unit_bytes;
+        if (need == 0) need = 1;
+        size_t pow2 = 1;  // few distinct slab sizes, so that files of different lengths share idle pipelines
+        while (pow2 < need) pow2 *= 2;
+        if (pow2 < blocks) blocks = pow2;
     }
     return blocks;
 }
 
 // Creating a pipeline allocates pinned host slabs and device buffers, which costs milliseconds --
 // more than transforming a small file.  Callers that process many files (the performance
-// benchmark, a server) mostly repeat the same geometry, so the most recently used pipelines are
-// kept and handed out again (the operating system reclaims them at process exit).
+// benchmark, a server) mostly repeat a few geometries, so idle pipelines are kept and handed out
+// again: any idle one for the same device, direction and block size that holds at least the
+// slab asked for will do.  The most recent kKeepAlways stay whatever their size, older ones
+// only while all idle slabs together stay within kIdleBytes (the operating system reclaims
+// them at process exit).
 class PipelineCache {
 public:
+    struct Lease {
+        bwtgpu_pipeline* p = nullptr;
+        size_t slab_blocks = 0;  // what the pipeline was created with (>= what was asked for)
+    };
     static PipelineCache& instance() {
         static PipelineCache* c = new PipelineCache;  // never destroyed: at exit the HIP runtime may be gone first
         return *c;
     }
-    bwtgpu_pipeline* acquire(int dev, int direction, size_t block_size, size_t slab_blocks, int depth) {
+    Lease acquire(int dev, int direction, size_t block_size, size_t slab_blocks, int depth) {
         {
             std::lock_guard<std::mutex> lock(mu_);
+            size_t best = idle_.size();
             for (size_t i = 0; i < idle_.size(); ++i) {
                 const Entry& e = idle_[i];
-                if (e.dev == dev && e.direction == direction && e.block_size == block_size &&
-                    e.slab_blocks == slab_blocks && e.depth == depth) {
-                    bwtgpu_pipeline* p = e.p;
-                    idle_.erase(idle_.begin() + (long)i);
-                    return p;
-                }
+                if (e.dev == dev && e.direction == direction && e.block_size == block_size && e.depth == depth &&
+                    e.slab_blocks >= slab_blocks && (best == idle_.size() || e.slab_blocks < idle_[best].slab_blocks))
+                    best = i;
+            }
+            if (best != idle_.size()) {
+                Lease l;
+                l.p = idle_[best].p;
+                l.slab_blocks = idle_[best].slab_blocks;
+                idle_.erase(idle_.begin() + (long)best);
+                return l;
             }
         }
-        return bwtgpu_pipeline_create(dev, direction, block_size, slab_blocks, depth);
+        Lease l;
+        l.p = bwtgpu_pipeline_create(dev, direction, block_size, slab_blocks, depth);
+        l.slab_blocks = slab_blocks;
+        return l;
     }
-    void release(bwtgpu_pipeline* p, int dev, int direction, size_t block_size, size_t slab_blocks, int depth) {
-        if (!p) return;
-        bwtgpu_pipeline* evict = nullptr;
+    void release(const Lease& l, int dev, int direction, size_t block_size, int depth) {
+        if (!l.p) return;
+        std::vector<bwtgpu_pipeline*> evict;
         {
             std::lock_guard<std::mutex> lock(mu_);
-            idle_.push_back({p, dev, direction, block_size, slab_blocks, depth});
-            if (idle_.size() > kKeep) {
-                evict = idle_.front().p;
+            idle_.push_back({l.p, dev, direction, block_size, l.slab_blocks, depth});
+            for (;;) {
+                size_t bytes = 0;
+                for (const Entry& e : idle_) bytes += e.slab_blocks * (e.block_size + 1) * (size_t)e.depth;
+                if (idle_.size() <= kKeepAlways || (idle_.size() <= kKeepMost && bytes <= kIdleBytes)) break;
+                evict.push_back(idle_.front().p);
                 idle_.erase(idle_.begin());
             }
         }
-        bwtgpu_pipeline_destroy(evict);
+        for (bwtgpu_pipeline* p : evict) bwtgpu_pipeline_destroy(p);
     }
 private:
     struct Entry {
@@ -93,7 +114,8 @@ private:
         size_t block_size, slab_blocks;
         int depth;
     };
-    static constexpr size_t kKeep = 4;
+    static constexpr size_t kKeepAlways = 4, kKeepMost = 48;
+    static constexpr size_t kIdleBytes = (size_t)256 << 20;
     std::mutex mu_;
     std::vector<Entry> idle_;
 };
@@ -111,6 +133,7 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
     const int depth = 2;
     const size_t unit = direction == BWTGPU_FORWARD ? block_size : block_size + 1;
     const size_t slab_blocks = slab_blocks_for(unit, remaining_bytes);
+    std::vector<PipelineCache::Lease> leases((size_t)ndev);
     std::vector<bwtgpu_pipeline*> pipes((size_t)ndev, nullptr);
     struct InFlight { int dev, slot; };
     std::deque<InFlight> inflight;
@@ -138,7 +161,8 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         if (inflight.size() == (size_t)ndev * (size_t)depth) drain_one();  // frees exactly (dev, slot)
         if (rc) break;
         if (!pipes[(size_t)dev]) {
-            pipes[(size_t)dev] = PipelineCache::instance().acquire(dev, direction, block_size, slab_blocks, depth);
+            leases[(size_t)dev] = PipelineCache::instance().acquire(dev, direction, block_size, slab_blocks, depth);
+            pipes[(size_t)dev] = leases[(size_t)dev].p;
             if (!pipes[(size_t)dev]) {
                 std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
                 rc = 1;
@@ -160,7 +184,7 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
     while (!inflight.empty()) drain_one();
     for (size_t d = 0; d < pipes.size(); ++d) {
         if (rc) bwtgpu_pipeline_destroy(pipes[d]);  // do not reuse a pipeline that reported an error
-        else PipelineCache::instance().release(pipes[d], (int)d, direction, block_size, slab_blocks, depth);
+        else PipelineCache::instance().release(leases[d], (int)d, direction, block_size, depth);
     }
     return rc;
 }

@@ -28,6 +28,19 @@ def gpu():
     yield
 
 
+@pytest.fixture(autouse=True, params=["auto", "block", "grid"])
+def forward_path(request):
+    """Every test runs three times: with the library choosing between the batch kernels and the
+    device-wide forward path by the shape of the input, and with either one forced."""
+    old = os.environ.get("BWTGPU_FORWARD_PATH")
+    os.environ["BWTGPU_FORWARD_PATH"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["BWTGPU_FORWARD_PATH"]
+    else:
+        os.environ["BWTGPU_FORWARD_PATH"] = old
+
+
 def test_known_answers(known_answers):
     for v in known_answers:
         data = bytes.fromhex(v["input_hex"])

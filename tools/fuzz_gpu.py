@@ -2,8 +2,11 @@
 
 usage: python tools/fuzz_gpu.py [trials] [seed] [big]
 Covers: alphabet sizes incl. powers of two (delimiter above / below / inside the alphabet),
-runs, periodic text, repeated blocks, lengths around the internal size thresholds, batches.
+runs, periodic text, repeated blocks, lengths around the internal size thresholds, batches;
+every trial through one of the forward paths (the batch kernels, the device-wide path, or the
+library's own choice).
 """
+import os
 import random
 import sys
 
@@ -18,6 +21,7 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 BIG_ONLY = len(sys.argv) > 3 and sys.argv[3] == "big"  # only long blocks and many-block batches
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 nrng = np.random.default_rng(rng.randrange(1 << 30))
+prng = random.Random(12345)  # forward path per trial, drawn apart so that the inputs do not depend on it
 SIZES = [1, 2, 3, 7, 16, 17, 18, 63, 64, 65, 129, 255, 256, 257, 1000, 4095, 4096, 4097, 4863, 4864, 4865, 5119, 5120,
          5121, 8191, 8192, 8193, 12345, 20000, 40000, 70000]
 
@@ -56,6 +60,8 @@ for t in range(trials):
         n = rng.randrange(280, 600) * rng.choice([4096, 8192, 12000])
     data, kind, sigma, base = make(n)
     mode = rng.random()
+    path = prng.choice(["auto", "auto", "block", "grid"])
+    os.environ["BWTGPU_FORWARD_PATH"] = path
     if 0.05 <= big < 0.10:
         bs = n // rng.randrange(270, 280)
         try:
@@ -85,7 +91,8 @@ for t in range(trials):
         bs = n
     if not (ok and back_ok):
         fails += 1
-        print("FAIL", t, "n", n, "bs", bs, kind, "sigma", sigma, "base", base, "delim", delim, "fwd", ok, "inv", back_ok, flush=True)
+        print("FAIL", t, "n", n, "bs", bs, kind, "sigma", sigma, "base", base, "delim", delim, "path", path, "fwd", ok,
+              "inv", back_ok, flush=True)
         if fails > 10:
             break
     if t % 100 == 99:
