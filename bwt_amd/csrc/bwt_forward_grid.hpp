@@ -34,7 +34,7 @@ constexpr int kGridVecs = 8;                           // 64-element vectors per
 constexpr int kGridChunk = kGridThreads * kGridVecs;   // elements a workgroup stages at a time
 constexpr int kGridDigitBits = 8;
 constexpr int kGridBins = 1 << kGridDigitBits;
-constexpr uint32_t kGridMaxTiles = 1024;               // workgroups of a sort or rank step
+constexpr uint32_t kGridMaxTiles = 1024;               // workgroups of a sort or rank step, at most
 constexpr int kGridScanThreads = 1024;
 constexpr int kGridRankVecs = 4;                       // consecutive elements per thread in the rank step
 constexpr int kGridRankChunk = kGridThreads * kGridRankVecs;
@@ -148,11 +148,11 @@ __global__ __launch_bounds__(kGridThreads) void grid_keys_kernel(GridArgs a, con
     }
 }
 
-// ---- device-wide LSD radix pass: count, scan, scatter ------------------------------------------
-// Tile t = elements [t*tile, (t+1)*tile); tile_hist[bin * ntiles + t] = its count of digit `bin`.
+// ---- device-wide LSD radix pass: count, scatter -------------------------------------------------
+// Tile t = elements [t*tile, (t+1)*tile); tile_hist[t * kGridBins + bin] = its count of digit `bin`.
 __global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t* __restrict__ key, uint32_t m,
-                                                                 uint32_t tile, uint32_t ntiles, uint32_t shift,
-                                                                 uint32_t mask, uint32_t* __restrict__ tile_hist) {
+                                                                 uint32_t tile, uint32_t shift, uint32_t mask,
+                                                                 uint32_t* __restrict__ tile_hist) {
     __shared__ uint32_t s_h[kGridBins];
     const uint32_t t = blockIdx.x;
     s_h[threadIdx.x] = 0;
@@ -161,29 +161,15 @@ __global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t*
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kGridThreads)
         atomicAdd(&s_h[(uint32_t)(key[i] >> shift) & mask], 1u);
     __syncthreads();
-    tile_hist[threadIdx.x * ntiles + t] = s_h[threadIdx.x];
+    tile_hist[t * kGridBins + threadIdx.x] = s_h[threadIdx.x];
 }
 
-// In-place exclusive prefix sum of v[0..len) by one workgroup.
-__global__ __launch_bounds__(kGridScanThreads) void grid_scan_kernel(uint32_t* __restrict__ v, uint32_t len) {
-    __shared__ uint32_t s_w[kGridScanThreads / kWave];
-    const uint32_t per = (len + kGridScanThreads - 1u) / kGridScanThreads;
-    const uint32_t lo = min(threadIdx.x * per, len), hi = min(lo + per, len);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += v[i];
-    uint32_t total;
-    uint32_t run = block_exclusive_scan<kGridScanThreads>(sum, s_w, total);
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t x = v[i];
-        v[i] = run;
-        run += x;
-    }
-}
-
-// Stable scatter of tile t by the digit: tile_hist (scanned) holds where the tile's elements of
-// every digit start.  A chunk of kGridChunk elements is ranked (wave ballot match + per-wave
-// counters, waves and vectors in element order), gathered by digit in LDS, and written out in
-// runs of equal digit.
+// Stable scatter of tile t by the digit.  Where the tile's elements of digit d start = the
+// elements of smaller digits in all tiles + those of digit d in the tiles before t: thread d
+// adds up its column of tile_hist (the whole table is a few hundred KiB at most and sits in the
+// L2; a separate scan launch costs more than these loads).  Then, per chunk of kGridChunk
+// elements: ranks by wave ballot match + per-wave counters (waves and vectors in element order),
+// the chunk gathered by digit in LDS, and written out in runs of equal digit.
 __global__ __launch_bounds__(kGridThreads) void grid_scatter_kernel(const uint64_t* __restrict__ key_in,
                                                                     const uint32_t* __restrict__ id_in,
                                                                     uint64_t* __restrict__ key_out,
@@ -200,7 +186,27 @@ __global__ __launch_bounds__(kGridThreads) void grid_scatter_kernel(const uint64
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint64_t lt = lanemask_lt();
     const uint32_t t = blockIdx.x;
-    s_cursor[tid] = tile_hist[(uint32_t)tid * ntiles + t];
+    {
+        uint32_t before = 0, all = 0;
+        uint32_t i = 0;
+        for (; i + 8u <= ntiles; i += 8u) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tile_hist[(i + (uint32_t)u) * kGridBins + (uint32_t)tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                all += v[u];
+                before += i + (uint32_t)u < t ? v[u] : 0u;
+            }
+        }
+        for (; i < ntiles; ++i) {
+            const uint32_t v = tile_hist[i * kGridBins + (uint32_t)tid];
+            all += v;
+            before += i < t ? v : 0u;
+        }
+        uint32_t total;
+        s_cursor[tid] = block_exclusive_scan<kGridThreads>(all, s_wsum, total) + before;
+    }
     const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
     for (uint32_t base = lo; base < hi; base += kGridChunk) {
         const uint32_t cnt = min(hi - base, (uint32_t)kGridChunk);

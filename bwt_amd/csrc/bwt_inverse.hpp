@@ -43,7 +43,9 @@ constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr uint32_t kRowMask = 0x007FFFFFu;   // successor row (n <= 2^21 < 2^23)
 constexpr uint32_t kSplitFlag = 0x00800000u; // this row starts a segment
 constexpr uint32_t kMinSplitShift = 4;       // rows between regular splitters: 16 or 32 (InvArgs::split_shift),
-constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain
+constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain when the batch has many blocks
+constexpr uint32_t kMultiMinRowsFew = 1280;  // ... and this is the bound when it has few: the chains are the whole cost then
+constexpr uint32_t kFewBlocks = 2048;
 constexpr int kSegThreads = 256;             // workgroup size of the segment kernels
                                              // staging slot per segment = 4 x that many bytes (InvArgs::slot)
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
@@ -59,6 +61,7 @@ struct InvArgs {
     uint32_t tstride;     // LF-table words per block (>= block_size+1)
     uint32_t seg_cap;     // segment slots per block (regular splitters + 1)
     uint32_t seg_wgs;     // workgroups of kSegThreads lanes that cover one block's segments
+    uint32_t multi_min_rows;  // blocks of at least this many rows are cut into segments
     uint32_t* T;          // nblocks * tstride words
     uint32_t* drow;       // per block: delimiter row or kNoRow
     uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
             if (sh.drow[i] != kNoRow) drow = sh.drow[i];
         // split the walk only when it is the plain single-delimiter case and long enough to pay
         const uint32_t mode = drow == kNoRow ? kModeNone
-                              : (sh.ndelim == 1u && n >= kMultiMinRows) ? kModeMulti : kModeSingle;
+                              : (sh.ndelim == 1u && n >= a.multi_min_rows) ? kModeMulti : kModeSingle;
         if (tid == 0) {
             a.drow[b] = drow;
             a.mode[b] = mode;

@@ -102,14 +102,12 @@ struct FwdGeom {
 };
 
 // ---- few large blocks: the device-wide path (bwt_forward_grid.hpp) --------------------------
-// Measured on MI355X: the device-wide path takes about 0.25 ms plus 1.3 us per KiB of the whole
-// batch (random bytes; text about three times that), the batch kernel 8.5 us per KiB of ONE block
-// (text: 25 us) as long as every block has a workgroup of its own -- so the former wins while the
-// batch is shorter than about six blocks, and for short blocks only with fewer still.
-constexpr size_t kGridMaxBlocks = 6;
-constexpr size_t kGridShortBlock = (size_t)128 << 10;  // blocks below this: at most kGridMaxShortBlocks
-constexpr size_t kGridMaxShortBlocks = 3;
-constexpr size_t kGridMinRows = 24576;       // below this the launches of the device-wide path cost more than they save
+// Measured on MI355X: the device-wide path takes about 0.15 ms plus 0.3 us per KiB of the whole
+// batch (random bytes; text about three times that, and 0.1 ms for every further round), the
+// batch kernel 0.2 ms plus 8.5 us per KiB of ONE block (text: 25 us) as long as every block has
+// a workgroup of its own.  The former wins for up to a few dozen blocks unless they are short.
+constexpr size_t kGridMaxBlocks = 32;
+constexpr size_t kGridMinBlock = 20000;      // bytes in the (longest) block
 constexpr size_t kGridMaxRows = (size_t)1 << 31;
 
 // BWTGPU_FORWARD_PATH=grid|block overrides the choice between the two forward paths (tests
@@ -147,11 +145,9 @@ GridGeom grid_geom(size_t total_len, size_t block_size) {
     return g;
 }
 
-size_t grid_block_limit(size_t block_size) { return block_size < kGridShortBlock ? kGridMaxShortBlocks : kGridMaxBlocks; }
-
 bool grid_shape(size_t total_len, size_t block_size) {
     const size_t nblocks = (total_len + block_size - 1) / block_size;
-    return nblocks <= grid_block_limit(block_size) && total_len + nblocks >= kGridMinRows;
+    return nblocks <= kGridMaxBlocks && std::min(total_len, block_size) >= kGridMinBlock;
 }
 
 FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
@@ -171,7 +167,7 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     const int forced = forced_forward_path();
     g.grid_path = total_len + g.nblocks <= kGridMaxRows && forced != 2 && (forced == 1 || grid_shape(total_len, block_size));
     if (forced != 2) {
-        const size_t most = forced == 1 ? total_len : std::min(total_len, grid_block_limit(block_size) * block_size);
+        const size_t most = forced == 1 ? total_len : std::min(total_len, kGridMaxBlocks * block_size);
         if (forced == 1 || grid_shape(most, block_size)) g.bytes = std::max(g.bytes, grid_geom(most, block_size).bytes);
     }
     return g;
@@ -181,7 +177,7 @@ struct InvGeom {
     size_t nblocks;
     uint32_t tstride;
     uint32_t build_grid;
-    uint32_t seg_cap, seg_wgs, chunk_cap, split_shift, slot;
+    uint32_t seg_cap, seg_wgs, chunk_cap, split_shift, slot, multi_min_rows;
     bool split;  // blocks are long enough for the segmented walk
     size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
@@ -194,7 +190,8 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.tstride = (uint32_t)round_up(longest, 64);
     const size_t max_wgs = (size_t)d.cus * (size_t)d.inv_wgs_per_cu;
     g.build_grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
-    g.split = longest >= kMultiMinRows;
+    g.multi_min_rows = g.nblocks < kFewBlocks ? kMultiMinRowsFew : kMultiMinRows;
+    g.split = longest >= g.multi_min_rows;
     // Splitter every 16 rows where the segment records of a block then still fit the LDS of the
     // stitch kernel and the block is long enough to pay for twice the segments (measured: 256 KiB
     // blocks gain, 64 KiB blocks lose); every 32 rows otherwise.
@@ -343,9 +340,13 @@ uint32_t* pinned_words() {
     return p;
 }
 
+// Elements per workgroup of a sort or rank step over m elements: one workgroup per compute unit
+// while that keeps tiles short (every scatter workgroup reads one count per digit and tile
+// before it starts), up to four per compute unit for long lists.
 uint32_t grid_tile(uint32_t m) {
-    const size_t per = ((size_t)m + kGridMaxTiles - 1) / kGridMaxTiles;
-    return (uint32_t)round_up(std::max<size_t>(per, 1), kGridChunk);
+    size_t tile = round_up(std::max<size_t>(((size_t)m + 255) / 256, 1), kGridChunk);
+    if (tile > 65536) tile = round_up(std::max<size_t>(65536, ((size_t)m + kGridMaxTiles - 1) / kGridMaxTiles), kGridChunk);
+    return (uint32_t)tile;
 }
 
 int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
@@ -392,10 +393,8 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
         const uint32_t tile = grid_tile(m), ntiles = (m + tile - 1) / tile;
         for (int shift = 0; shift < bits; shift += kGridDigitBits) {
             const uint32_t mask = (1u << std::min(kGridDigitBits, bits - shift)) - 1u;
-            hipLaunchKernelGGL(grid_hist_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, key[cur], m, tile, ntiles,
+            hipLaunchKernelGGL(grid_hist_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, key[cur], m, tile,
                                (uint32_t)shift, mask, a.tile_hist);
-            hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(kGridScanThreads), 0, s, a.tile_hist,
-                               (uint32_t)kGridBins * ntiles);
             hipLaunchKernelGGL(grid_scatter_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, key[cur], id[cur],
                                key[cur ^ 1], id[cur ^ 1], m, tile, ntiles, (uint32_t)shift, mask, a.tile_hist);
             HIP_TRY(hipGetLastError());
@@ -631,6 +630,7 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.split_shift = g.split_shift;
     a.slot = g.slot;
     a.seg_wgs = g.seg_wgs;
+    a.multi_min_rows = g.multi_min_rows;
     a.T = (uint32_t*)(ws + g.t_off);
     a.drow = (uint32_t*)(ws + g.drow_off);
     a.mode = (uint32_t*)(ws + g.mode_off);

@@ -48,4 +48,13 @@ for f, delim in [("alice29.txt", 0), ("ptt5", 10), ("lcet10.txt", 0), ("plrabn12
     raw = open(os.path.join("data/canterbury_corpus", f), "rb").read()
     for bs in [65536, 1048576]:
         check(f, raw, bs, delim)
+for f, delim, sizes in [("fields.c", 0, [16384]), ("xargs.1", 0, [16384]), ("grammar.lsp", 0, [16384]),
+                        ("lcet10.txt", 0, [16384, 32768, 49152]), ("plrabn12.txt", 0, [16384, 32768, 49152]),
+                        ("ptt5", 10, [16384, 32768]), ("alice29.txt", 0, [8192, 16384, 32768])]:
+    raw = open(os.path.join("data/canterbury_corpus", f), "rb").read()
+    for bs in sizes:
+        check(f, raw, bs, delim)
+for n, bs in [(4 << 20, 262144), (6 << 20, 524288), (16 << 20, 1048576), (2 << 20, 2097151)]:
+    d = synth.generate("acgt", 5, 0, n).tobytes()
+    check("acgt many", d, bs, 0)
 print("ALL OK")
