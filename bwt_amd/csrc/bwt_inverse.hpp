@@ -16,8 +16,13 @@
 //
 // The walk itself is a pointer chase of n dependent loads; one chain per block leaves the
 // memory system idle, so a well-formed block (exactly one delimiter) is cut into segments:
-// every 16th or 32nd row and the delimiter row are "splitters"; one lane per splitter
-// walks until it reaches the next splitter (whose own byte still belongs to it).
+// one row in 16 or 32 and the delimiter row are "splitters"; one lane per splitter walks until
+// it reaches the next splitter (whose own byte still belongs to it).  Which rows: those whose
+// image under row -> row * A mod n (A coprime to n, A / n close to the golden ratio) is below
+// n / 16 -- the image is the segment's id.  Every 16th row would do for random text, but in the
+// long runs of repetitive input the walk moves by a constant row distance d per step, and with
+// d even it can go thousands of steps without meeting a multiple of 16; under the
+// multiplication any such progression keeps meeting the splitter interval.
 //   bwt_inverse_walk_segments_kernel  every segment's length, the splitter it runs into and its
 //                                     bytes (into a 128-byte staging slot per segment; the few
 //                                     longer ones chain chunks from a per-block pool)
@@ -77,6 +82,9 @@ struct InvArgs {
     uint8_t* pool;        // nblocks * chunk_cap * slot
     uint32_t* lens;       // per block: text length or BWTGPU_LEN_NO_DELIMITER
     uint32_t* queue;      // [0] next block index to hand out
+    // splitter map row -> row * mul mod n and its inverse id -> id * inv mod n; [0] for full
+    // blocks (n = block_size + 1), [1] for the last block of the batch
+    uint32_t split_mul[2], split_inv[2];
 };
 
 template <int NT>
@@ -95,9 +103,13 @@ __device__ __forceinline__ uint32_t inv_block_len(const InvArgs& a, uint32_t b) 
     return rem < (uint64_t)a.block_size + 1u ? (uint32_t)rem : a.block_size + 1u;
 }
 
-// Regular splitters of a block of n rows: rows 0, stride, 2 stride, ...
+// Regular splitters of a block of n rows: one row in 2^split_shift.
 __device__ __host__ __forceinline__ uint32_t regular_splitters(uint32_t n, uint32_t split_shift) {
     return (n + (1u << split_shift) - 1u) >> split_shift;
+}
+// Row -> splitter id (a splitter iff below regular_splitters) and id -> row.
+__device__ __forceinline__ uint32_t mul_mod(uint32_t x, uint32_t m, uint32_t n) {
+    return (uint32_t)(((uint64_t)x * m) % n);
 }
 
 template <int NT>
@@ -174,6 +186,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         const bool split = mode == kModeMulti;
         // pass 2: LF table
         uint32_t* myoff = sh.hist + w * 256;
+        const uint32_t nreg = regular_splitters(n, a.split_shift);
+        const uint32_t mul = a.split_mul[b + 1u == a.nblocks ? 1 : 0];
+        const uint32_t step = mul_mod(kWave, mul, n);          // image distance of rows 64 apart
+        uint32_t image = mul_mod(lo + (uint32_t)lane, mul, n);  // of row base + lane
         for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
             uint32_t cs[U];
 #pragma unroll
@@ -191,8 +207,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
                     compiler_fence();  // every lane has read its offset before the leaders advance it
                     if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
                     compiler_fence();
-                    const uint32_t flag = (split && ((k & ((1u << a.split_shift) - 1u)) == 0u || k == drow)) ? kSplitFlag : 0u;
+                    const uint32_t flag = (split && (image < nreg || k == drow)) ? kSplitFlag : 0u;
                     if (valid) T[k] = (b0 + rk) | flag | (c << 24);
+                    image += step;
+                    image -= image >= n ? n : 0u;
                 }
             }
         }
@@ -307,8 +325,8 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
 // the grid serves block (w / 8 / seg_wgs) * 8 + w % 8: all workgroups of one block share an
 // XCD, and an XCD works through its blocks in order.  (If the hardware placed workgroups
 // differently only the cache locality would suffer.)
-// Segment j < regular_splitters(n) starts at row j * stride, j == regular_splitters(n) starts
-// at the delimiter row.  (A regular splitter that IS the delimiter row is left to the latter.)
+// Segment j < regular_splitters(n) starts at the row whose image is j, j == regular_splitters(n)
+// starts at the delimiter row.  (A regular splitter that IS the delimiter row is left to the latter.)
 __device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, uint32_t& j) {
     const uint32_t w = blockIdx.x, x = w & 7u, q = w >> 3;
     b = (q / a.seg_wgs) * 8u + x;
@@ -327,7 +345,8 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
     const uint32_t drow = a.drow[b];
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     if (a.split_shift != kMinSplitShift) a.seg_pos[sb + j] = kNoPos;  // the LDS stitch writes every position itself
-    const uint32_t start = j < nreg ? (j << a.split_shift) : drow;
+    const int last = b + 1u == a.nblocks ? 1 : 0;
+    const uint32_t start = j < nreg ? mul_mod(j, a.split_inv[last], n) : drow;
     if (j < nreg && start == drow) {
         a.seg[sb + j] = make_uint2(0u, j);
         return;
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
         else { val.x = q1; val.y = q2; val.z = q3; val.w = acc; }
         __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t & ~15u) & (a.slot - 1u))));
     }
-    a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : (stop >> a.split_shift));
+    a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : mul_mod(stop, a.split_mul[last], n));
 }
 
 // Orders the segments of every split block: start at the delimiter row's segment, follow the

@@ -182,6 +182,34 @@ struct InvGeom {
     size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
 
+// Multiplier of the splitter map row -> row * mul mod n of the inverse (bwt_inverse.hpp) and its
+// inverse modulo n: mul / n near the golden ratio, coprime to n.
+void splitter_map(uint32_t n, uint32_t* mul, uint32_t* inv) {
+    *mul = *inv = 1;
+    if (n < 3) return;
+    uint64_t m = (uint64_t)((double)n * 0.6180339887498949);
+    if (m < 1) m = 1;
+    auto gcd = [](uint64_t x, uint64_t y) {
+        while (y) {
+            const uint64_t t = x % y;
+            x = y;
+            y = t;
+        }
+        return x;
+    };
+    while (gcd(m, n) != 1) ++m;  // reaches n - 1 at the latest
+    // extended Euclid: m * x == 1 (mod n)
+    int64_t r0 = n, r1 = (int64_t)m, x0 = 0, x1 = 1;
+    while (r1) {
+        const int64_t q = r0 / r1, r2 = r0 - q * r1, x2 = x0 - q * x1;
+        r0 = r1; r1 = r2;
+        x0 = x1; x1 = x2;
+    }
+    if (x0 < 0) x0 += n;
+    *mul = (uint32_t)m;
+    *inv = (uint32_t)x0;
+}
+
 InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     InvGeom g;
     const size_t chunk = block_size + 1;
@@ -631,6 +659,11 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.slot = g.slot;
     a.seg_wgs = g.seg_wgs;
     a.multi_min_rows = g.multi_min_rows;
+    {
+        const size_t unit = block_size + 1;
+        splitter_map((uint32_t)std::min(total, unit), &a.split_mul[0], &a.split_inv[0]);
+        splitter_map((uint32_t)(total - (g.nblocks - 1) * unit), &a.split_mul[1], &a.split_inv[1]);
+    }
     a.T = (uint32_t*)(ws + g.t_off);
     a.drow = (uint32_t*)(ws + g.drow_off);
     a.mode = (uint32_t*)(ws + g.mode_off);
