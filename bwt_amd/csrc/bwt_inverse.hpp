@@ -218,6 +218,159 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
     }
 }
 
+// ---- LF table of FEW LARGE blocks: many workgroups per block --------------------------------------
+// One workgroup per block leaves the chip idle when the batch has only a few blocks.  Here a
+// block is cut into tiles of `tile_rows` rows; a first kernel counts the byte values of every
+// tile (and finds the delimiter rows), the second gives every tile its own workgroup, which
+// derives its start offsets from the counts of all tiles of its block (thread c adds up column
+// c: C[c] plus the occurrences of c in the tiles before) and then ranks its rows exactly as
+// bwt_inverse_build_kernel does.
+struct InvTileArgs {
+    uint32_t tile_rows;       // rows per tile (multiple of 64 * waves)
+    uint32_t tiles_per_block;
+    uint32_t* tile_hist;      // nblocks * tiles_per_block * 256
+    uint32_t* dacc;           // per block: [0] last delimiter row + 1 (0 = none), [1] delimiters
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void bwt_inverse_tile_hist_kernel(InvArgs a, InvTileArgs ta) {
+    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_last, s_cnt;
+    const int tid = threadIdx.x;
+    const uint32_t b = blockIdx.x / ta.tiles_per_block, t = blockIdx.x % ta.tiles_per_block;
+    const uint32_t n = inv_block_len(a, b);
+    const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
+    for (int i = tid; i < 256; i += NT) s_h[i] = 0;
+    if (tid == 0) s_last = s_cnt = 0;
+    __syncthreads();
+    const uint32_t lo = min(t * ta.tile_rows, n), hi = min(lo + ta.tile_rows, n);
+    uint32_t last = 0, cnt = 0;
+    for (uint32_t k = lo + tid; k < hi; k += NT) {
+        const uint32_t c = L[k];
+        atomicAdd(&s_h[c], 1u);
+        if (c == a.delim) {
+            last = k + 1u;
+            ++cnt;
+        }
+    }
+    if (cnt) {
+        atomicMax(&s_last, last);
+        atomicAdd(&s_cnt, cnt);
+    }
+    __syncthreads();
+    uint32_t* __restrict__ h = ta.tile_hist + (uint64_t)blockIdx.x * 256u;
+    for (int i = tid; i < 256; i += NT) h[i] = s_h[i];
+    if (tid == 0 && s_cnt) {
+        atomicMax(&ta.dacc[2u * b], s_last);
+        atomicAdd(&ta.dacc[2u * b + 1u], s_cnt);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, InvTileArgs ta) {
+    constexpr int W = NT / kWave;
+    static_assert(NT >= 256, "one thread per symbol in the scan");
+    __shared__ InvShared<NT> sh;
+    __shared__ uint32_t s_base[256];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t b = blockIdx.x / ta.tiles_per_block, t = blockIdx.x % ta.tiles_per_block;
+    const uint32_t n = inv_block_len(a, b);
+    const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
+    uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    const uint32_t tlo = min(t * ta.tile_rows, n), thi = min(tlo + ta.tile_rows, n);
+    for (int i = tid; i < W * 256; i += NT) sh.hist[i] = 0;
+    // where the rows of this tile with byte value c go: C[c] + occurrences in the tiles before
+    {
+        uint32_t before = 0, all = 0;
+        if (tid < 256) {
+            const uint32_t* __restrict__ h = ta.tile_hist + (uint64_t)b * ta.tiles_per_block * 256u + (uint32_t)tid;
+            uint32_t i = 0;
+            for (; i + 8u <= ta.tiles_per_block; i += 8u) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = h[(i + (uint32_t)u) * 256u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    all += v[u];
+                    before += i + (uint32_t)u < t ? v[u] : 0u;
+                }
+            }
+            for (; i < ta.tiles_per_block; ++i) {
+                const uint32_t v = h[i * 256u];
+                all += v;
+                before += i < t ? v : 0u;
+            }
+        }
+        uint32_t total;
+        const uint32_t c0 = block_exclusive_scan<NT>(all, sh.wsum, total);
+        if (tid < 256) s_base[tid] = c0 + before;
+    }
+    const uint32_t dlast = ta.dacc[2u * b], ndelim = ta.dacc[2u * b + 1u];
+    const uint32_t drow = dlast ? dlast - 1u : kNoRow;
+    const uint32_t mode = drow == kNoRow ? kModeNone : (ndelim == 1u && n >= a.multi_min_rows) ? kModeMulti : kModeSingle;
+    if (t == 0 && tid == 0) {
+        a.drow[b] = drow;
+        a.mode[b] = mode;
+        a.pool_used[b] = 0;
+    }
+    const bool split = mode == kModeMulti;
+    __syncthreads();
+    Chunking ck;
+    ck.init(thi - tlo, W);
+    const uint32_t lo = min(tlo + (uint32_t)w * ck.chunk, thi), hi = min(lo + ck.chunk, thi);
+    constexpr int U = 4;
+    // pass 1: byte counts of every wave's share of the tile
+    for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+        uint32_t cs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cs[u] = L[min(base0 + (uint32_t)(u * kWave + lane), n - 1u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base0 + (uint32_t)(u * kWave + lane) < hi) atomicAdd(&sh.hist[w * 256 + cs[u]], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t run = s_base[tid];
+        for (int i = 0; i < W; ++i) {
+            const uint32_t v = sh.hist[i * 256 + tid];
+            sh.hist[i * 256 + tid] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    // pass 2: LF table
+    uint32_t* myoff = sh.hist + w * 256;
+    const uint32_t nreg = regular_splitters(n, a.split_shift);
+    const uint32_t mul = a.split_mul[b + 1u == a.nblocks ? 1 : 0];
+    const uint32_t step = mul_mod(kWave, mul, n);
+    uint32_t image = mul_mod(lo + (uint32_t)lane, mul, n);
+    for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+        uint32_t cs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cs[u] = L[min(base0 + (uint32_t)(u * kWave + lane), n - 1u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t base = base0 + (uint32_t)(u * kWave);
+            if (base < hi) {  // wave-uniform
+                const uint32_t k = base + lane;
+                const bool valid = k < hi;
+                const uint32_t c = cs[u];
+                const uint64_t peers = match_digit<8>(c, valid);
+                const uint32_t rk = __popcll(peers & lt);
+                const uint32_t b0 = myoff[c];
+                compiler_fence();  // every lane has read its offset before the leaders advance it
+                if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
+                compiler_fence();
+                const uint32_t flag = (split && (image < nreg || k == drow)) ? kSplitFlag : 0u;
+                if (valid) T[k] = (b0 + rk) | flag | (c << 24);
+                image += step;
+                image -= image >= n ? n : 0u;
+            }
+        }
+    }
+}
+
 // Collects bytes that arrive back to front and stores them below `end`: whole aligned 16-byte
 // groups where possible, single dwords and bytes at the two ragged ends, never a byte outside
 // [end - count, end).

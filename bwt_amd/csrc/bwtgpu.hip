@@ -27,6 +27,8 @@ constexpr size_t kWideMinBlock = 8192; // shorter blocks do not pay for the wide
 constexpr int kFwdThreads = 256;   // forward: threads per workgroup (4 waves, each with an 8 KiB LDS staging tile)
 constexpr int kInvThreads = 256;   // inverse table build: threads per workgroup
 constexpr size_t kHeaderBytes = 256;  // workspace header: work queue + status words
+constexpr size_t kInvTiledMaxBlocks = 128;   // inverse: batches of at most this many blocks ...
+constexpr size_t kInvTiledMinRows = 16384;   // ... of at least this many rows build their LF tables tile by tile
 
 thread_local char g_err[512] = "";
 
@@ -179,6 +181,9 @@ struct InvGeom {
     uint32_t build_grid;
     uint32_t seg_cap, seg_wgs, chunk_cap, split_shift, slot, multi_min_rows;
     bool split;  // blocks are long enough for the segmented walk
+    bool tiled;  // few large blocks: the LF tables are built by many workgroups per block
+    uint32_t tile_rows, tiles_per_block;
+    size_t dacc_off, thist_off;
     size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
 
@@ -230,12 +235,19 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.seg_cap = g.split ? regular_splitters((uint32_t)longest, g.split_shift) + 1u : 1u;
     g.seg_wgs = (g.seg_cap + kSegThreads - 1) / kSegThreads;
     g.chunk_cap = g.split ? (uint32_t)(longest / g.slot) + 8u : 1u;
+    // One workgroup builds a 1 MiB block's table in about 2 ms; with fewer blocks than compute
+    // units the tables are built tile by tile instead.
+    g.tiled = g.nblocks <= kInvTiledMaxBlocks && longest >= kInvTiledMinRows;
+    g.tile_rows = (uint32_t)round_up(std::max<size_t>(4096, (longest + 255) / 256), 256);
+    g.tiles_per_block = (uint32_t)((longest + g.tile_rows - 1) / g.tile_rows);
     size_t off = kHeaderBytes;
     auto take = [&](size_t bytes) {
         const size_t at = off;
         off = round_up(off + bytes, 256);
         return at;
     };
+    g.dacc_off = take(g.tiled ? g.nblocks * 8 : 0);  // directly after the header: cleared with it
+    g.thist_off = take(g.tiled ? g.nblocks * (size_t)g.tiles_per_block * 256 * 4 : 0);
     g.drow_off = take(g.nblocks * 4);
     g.mode_off = take(g.nblocks * 4);
     g.used_off = take(g.nblocks * 4);
@@ -644,7 +656,7 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     if (g.nblocks > 0xFFFFFFF0ull) return fail(BWTGPU_ERR_INVALID, "too many blocks in one batch");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
+    HIP_TRY(hipMemsetAsync(d_workspace, 0, g.tiled ? g.dacc_off + g.nblocks * 8 : kHeaderBytes, s));
     InvArgs a;
     uint8_t* ws = (uint8_t*)d_workspace;
     a.in = d_in;
@@ -684,7 +696,18 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         HIP_TRY(hipGetLastError());
         return BWTGPU_OK;
     }
-    hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
+    if (g.tiled) {
+        InvTileArgs ta;
+        ta.tile_rows = g.tile_rows;
+        ta.tiles_per_block = g.tiles_per_block;
+        ta.tile_hist = (uint32_t*)(ws + g.thist_off);
+        ta.dacc = (uint32_t*)(ws + g.dacc_off);
+        const uint32_t tiles = (uint32_t)(g.nblocks * g.tiles_per_block);
+        hipLaunchKernelGGL(bwt_inverse_tile_hist_kernel<kInvThreads>, dim3(tiles), dim3(kInvThreads), 0, s, a, ta);
+        hipLaunchKernelGGL(bwt_inverse_tile_build_kernel<kInvThreads>, dim3(tiles), dim3(kInvThreads), 0, s, a, ta);
+    } else {
+        hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
+    }
     HIP_TRY(hipGetLastError());
     const uint32_t per_block_grid = (uint32_t)((g.nblocks + kWave - 1) / kWave);
     hipLaunchKernelGGL(bwt_inverse_walk_kernel, dim3(per_block_grid), dim3(kWave), 0, s, a);
