@@ -39,6 +39,7 @@ SYMBOLS = [
     "bwtgpu_alloc_host", "bwtgpu_free_host",
     "bwtgpu_pipeline_create", "bwtgpu_pipeline_input", "bwtgpu_pipeline_input_capacity",
     "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
+    "bwtgpu_pipeline_upload_presence",
 ]
 
 
@@ -90,6 +91,8 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_pipeline_submit.argtypes, L.bwtgpu_pipeline_submit.restype = [_vp, _i, _sz, _u8], _i
     L.bwtgpu_pipeline_collect.argtypes = [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]
     L.bwtgpu_pipeline_collect.restype = _i
+    L.bwtgpu_pipeline_upload_presence.argtypes = [_vp, _i, _sz, ctypes.POINTER(ctypes.c_uint32)]
+    L.bwtgpu_pipeline_upload_presence.restype = _i
     L.bwtgpu_pipeline_destroy.argtypes, L.bwtgpu_pipeline_destroy.restype = [_vp], None
     _lib = L
     return L

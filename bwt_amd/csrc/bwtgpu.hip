@@ -490,6 +490,7 @@ struct PipeSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     size_t in_bytes = 0;
+    size_t resident = 0;  // bytes of h_in already uploaded by bwtgpu_pipeline_upload_presence
     bool busy = false;
 };
 
@@ -531,10 +532,10 @@ int pipeline_alloc(bwtgpu_pipeline* p, int depth) {
     for (PipeSlot& s : p->slots) {
         HIP_TRY(hipHostMalloc((void**)&s.h_in, p->in_cap, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&s.h_out, p->out_cap, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void**)&s.h_lens, (p->slab_blocks + 2) * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&s.h_lens, (p->slab_blocks + 8) * 4, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void**)&s.d_in, p->in_cap));
         HIP_TRY(hipMalloc((void**)&s.d_out, p->out_cap));
-        HIP_TRY(hipMalloc((void**)&s.d_lens, (p->slab_blocks + 2) * 4));
+        HIP_TRY(hipMalloc((void**)&s.d_lens, (p->slab_blocks + 8) * 4));
         HIP_TRY(hipMalloc(&s.d_ws, p->ws_bytes));
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -940,8 +941,10 @@ int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t d
     HIP_TRY(hipSetDevice(p->device));
     s.in_bytes = bytes;
     p->delimiter = delimiter;
+    const bool uploaded = bytes && s.resident == bytes;
+    s.resident = 0;
     if (bytes) {
-        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
+        if (!uploaded) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
         int rc;
         if (p->direction == BWTGPU_FORWARD) {
             rc = bwtgpu_forward_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_ws,
@@ -961,6 +964,26 @@ int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t d
     }
     HIP_TRY(hipEventRecord(s.done, s.stream));
     s.busy = true;
+    return BWTGPU_OK;
+}
+
+int bwtgpu_pipeline_upload_presence(bwtgpu_pipeline* p, int slot, size_t bytes, uint32_t presence_out[8]) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size() || !presence_out) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    PipeSlot& s = p->slots[(size_t)slot];
+    if (s.busy) return fail(BWTGPU_ERR_INVALID, "slot %d is in flight", slot);
+    if (bytes > p->in_cap) return fail(BWTGPU_ERR_INVALID, "%zu bytes exceed the slab capacity %zu", bytes, p->in_cap);
+    memset(presence_out, 0, 32);
+    s.resident = 0;
+    if (bytes == 0) return BWTGPU_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemsetAsync(s.d_lens, 0, 32, s.stream));
+    int rc = bwtgpu_presence_device(p->device, s.d_in, bytes, s.d_lens, s.stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(s.h_lens, s.d_lens, 32, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    memcpy(presence_out, s.h_lens, 32);
+    s.resident = bytes;
     return BWTGPU_OK;
 }
 

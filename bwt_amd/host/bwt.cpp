@@ -57,7 +57,68 @@ std::string bwt_forward(const std::string& input, char delimiter) {
     return out;
 }
 
+// A regular file that fits one slab is read and uploaded ONCE: the delimiter search runs on the
+// uploaded bytes and the transform then starts from them.  Returns -1 when the file does not
+// qualify (the caller then takes the general two-pass route), else the result code.
+static int forward_single_slab(const char* input_file, const char* output_file, size_t block_size) {
+    if (block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE) return -1;
+    FileProcessor reader(input_file, "", block_size);
+    if (!reader.is_open() || !reader.input_is_regular() || reader.input_size() == 0) return -1;
+    const size_t size = reader.input_size();
+    const size_t slab_blocks = bwt_host::slab_blocks_for(block_size, size);
+    if (slab_blocks * block_size < size || bwt_host::device_budget() <= 0) return -1;
+    const int depth = 2;
+    bwt_host::PipelineCache& cache = bwt_host::PipelineCache::instance();
+    bwt_host::PipelineCache::Lease lease = cache.acquire(0, BWTGPU_FORWARD, block_size, slab_blocks, depth);
+    if (!lease.p) return -1;
+    bwtgpu_pipeline* p = lease.p;
+    int rc = 1;
+    bool reusable = true;
+    do {
+        const size_t got = reader.read_bytes(reinterpret_cast<char*>(bwtgpu_pipeline_input(p, 0)),
+                                             bwtgpu_pipeline_input_capacity(p));
+        char extra;
+        if (got != size || reader.read_char(extra)) {  // the file changed under us: let the general route handle it
+            rc = -1;
+            break;
+        }
+        uint32_t mask[8];
+        if (bwtgpu_pipeline_upload_presence(p, 0, got, mask) != BWTGPU_OK) {
+            std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+            reusable = false;
+            break;
+        }
+        const int delimiter_byte = bwtgpu_lowest_clear_bit(mask);
+        if (delimiter_byte < 0) {
+            std::cerr << "Error: Cannot find a unique delimiter (all 256 byte values appear in file)" << std::endl;
+            break;
+        }
+        const char delimiter = static_cast<char>(delimiter_byte);
+        FileProcessor writer(input_file, output_file, block_size);
+        if (!writer.is_open()) break;
+        const uint8_t* out = nullptr;
+        size_t n = 0;
+        if (bwtgpu_pipeline_submit(p, 0, got, static_cast<uint8_t>(delimiter)) != BWTGPU_OK ||
+            bwtgpu_pipeline_collect(p, 0, &out, &n) != BWTGPU_OK) {
+            std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+            reusable = false;
+            break;
+        }
+        if (!writer.write_bytes(&delimiter, 1) || !writer.write_bytes(reinterpret_cast<const char*>(out), n)) {
+            std::cerr << "Error: short write to the output file" << std::endl;
+            break;
+        }
+        writer.close();
+        rc = 0;
+    } while (false);
+    if (reusable) cache.release(lease, 0, BWTGPU_FORWARD, block_size, depth);
+    else bwtgpu_pipeline_destroy(p);
+    return rc;
+}
+
 int bwt_forward_process_file(const char* input_file, const char* output_file, size_t block_size) {
+    const int fast = forward_single_slab(input_file, output_file, block_size);
+    if (fast >= 0) return fast;
     const int delimiter_byte = find_unique_char(input_file);
     if (delimiter_byte == -1) {
         std::cerr << "Error: Cannot find a unique delimiter (all 256 byte values appear in file)" << std::endl;

@@ -44,8 +44,10 @@ inline size_t slab_blocks_for(size_t unit_bytes, size_t file_bytes) {
     if (file_bytes) {
         size_t need = (file_bytes + unit_bytes - 1) / unit_bytes;
         if (need == 0) need = 1;
-        size_t pow2 = 1;  // few distinct slab sizes, so that files of different lengths share idle pipelines
-        while (pow2 < need) pow2 *= 2;
+        // few distinct slab sizes, none tiny, so that files of different lengths share idle pipelines
+        const size_t kSmallSlab = (size_t)4 << 20;
+        size_t pow2 = 1;
+        while (pow2 < need || pow2 * unit_bytes < kSmallSlab) pow2 *= 2;
         if (pow2 < blocks) blocks = pow2;
     }
     return blocks;

@@ -118,6 +118,12 @@ uint8_t* bwtgpu_pipeline_input(bwtgpu_pipeline* p, int slot);
 size_t bwtgpu_pipeline_input_capacity(const bwtgpu_pipeline* p);
 /* Enqueues upload + transform + download of the first `bytes` bytes of the slot's input. */
 int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter);
+/* Uploads the first `bytes` bytes of the slot's input and returns their byte-presence mask
+ * (as bwtgpu_find_unused_byte does; synchronous).  A bwtgpu_pipeline_submit of the same slot
+ * with the same byte count that follows uses the uploaded bytes instead of uploading again:
+ * a file that fits one slab is read and uploaded once for both the delimiter search
+ * (reference src/bwt.cpp:19-47 reads the file a first time for it) and the transform. */
+int bwtgpu_pipeline_upload_presence(bwtgpu_pipeline* p, int slot, size_t bytes, uint32_t presence_out[8]);
 /* Blocks until the slot is done; *out / *out_bytes describe its pinned result, valid until
  * the slot is submitted again.  Inverse results are already compacted. */
 int bwtgpu_pipeline_collect(bwtgpu_pipeline* p, int slot, const uint8_t** out, size_t* out_bytes);
