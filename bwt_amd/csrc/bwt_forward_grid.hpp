@@ -414,4 +414,159 @@ __global__ __launch_bounds__(kGridThreads) void grid_rank_apply_kernel(GridArgs 
     }
 }
 
+// ---- the last rounds in one launch ----------------------------------------------------------------
+// Once few suffixes are still tied, a round's dozen launches and the host's look at the count
+// cost far more than its work.  One workgroup then finishes the job alone: the list stays in
+// registers and LDS (kGridFinishVecs elements per thread), every round builds the keys, sorts
+// them with the same ballot-match passes as grid_scatter_kernel, ranks them with the same run
+// logic as grid_rank_apply_kernel, and keeps the still-tied suffixes for the next round, until
+// none is left.  Ranks go through global memory (other suffixes' keys read them); a workgroup
+// barrier orders those writes before the next round's reads.
+constexpr int kGridFinishThreads = 1024;
+constexpr int kGridFinishVecs = 8;
+constexpr uint32_t kGridFinishCap = kGridFinishThreads * kGridFinishVecs;
+
+struct GridFinishShared {
+    uint64_t key[kGridFinishCap];
+    uint32_t id[kGridFinishCap];
+    uint32_t wcnt[kGridFinishThreads / kWave][kGridBins];
+    uint32_t wsum[kGridFinishThreads / kWave];
+};
+
+__global__ __launch_bounds__(kGridFinishThreads) void grid_finish_kernel(GridArgs a, const uint32_t* __restrict__ id_in,
+                                                                         uint32_t m, uint64_t h, uint32_t b1,
+                                                                         uint32_t b2) {
+    constexpr int NT = kGridFinishThreads, W = NT / kWave, V = kGridFinishVecs;
+    __shared__ GridFinishShared sh;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t lt = lanemask_lt();
+    uint64_t k[V];
+    uint32_t ids[V], lr[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+        ids[v] = e < m ? id_in[e] : 0u;
+    }
+    for (int round = 0; m && round < 64; ++round, h *= 2) {
+        // keys of the round
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+            k[v] = 0;
+            if (e < m) {
+                const uint32_t g = ids[v];
+                const GridPos p = grid_pos(a, g);
+                uint32_t r2 = 0;
+                if ((uint64_t)p.off + h <= (uint64_t)p.len) r2 = a.rank[g + (uint32_t)h] - (g - p.off) + 1u;
+                k[v] = ((uint64_t)a.rank[g] << b2) | r2;
+            }
+        }
+        // LSD radix sort, the list going from registers through LDS back to registers every pass
+#pragma unroll 1
+        for (uint32_t shift = 0; shift < b1 + b2; shift += kGridDigitBits) {
+            const uint32_t mask = (1u << min((uint32_t)kGridDigitBits, b1 + b2 - shift)) - 1u;
+            for (int i = tid; i < W * kGridBins; i += NT) (&sh.wcnt[0][0])[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+                const bool valid = e < m;
+                const uint32_t d = (uint32_t)(k[v] >> shift) & mask;
+                const uint64_t peers = match_digit<kGridDigitBits>(d, valid);
+                const uint32_t rk = __popcll(peers & lt);
+                const uint32_t c0 = sh.wcnt[w][d];
+                compiler_fence();  // every lane has read the count before the leaders advance it
+                if (valid && rk == 0) sh.wcnt[w][d] = c0 + (uint32_t)__popcll(peers);
+                compiler_fence();
+                lr[v] = c0 + rk;
+            }
+            __syncthreads();
+            {   // thread d < 256: where digit d starts, per wave
+                uint32_t tot = 0;
+                if (tid < kGridBins)
+                    for (int i = 0; i < W; ++i) tot += sh.wcnt[i][tid];
+                uint32_t total;
+                uint32_t run = block_exclusive_scan<NT>(tot, sh.wsum, total);
+                if (tid < kGridBins)
+                    for (int i = 0; i < W; ++i) {
+                        const uint32_t c = sh.wcnt[i][tid];
+                        sh.wcnt[i][tid] = run;
+                        run += c;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+                if (e < m) {
+                    const uint32_t p = sh.wcnt[w][(uint32_t)(k[v] >> shift) & mask] + lr[v];
+                    sh.key[p] = k[v];
+                    sh.id[p] = ids[v];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+                k[v] = e < m ? sh.key[e] : 0ull;
+                ids[v] = e < m ? sh.id[e] : 0u;
+            }
+            __syncthreads();
+        }
+        // ranks: thread t takes the V consecutive positions from t * V of the sorted list in LDS
+        const uint32_t j0 = (uint32_t)tid * V;
+        uint64_t q[V + 2];
+        uint32_t gs[V];
+#pragma unroll
+        for (int i = 0; i < V + 2; ++i) {
+            const uint32_t j = j0 + (uint32_t)i - 1u;
+            q[i] = (j0 + (uint32_t)i >= 1u && j < m) ? sh.key[j] : 0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) gs[i] = j0 + (uint32_t)i < m ? sh.id[j0 + (uint32_t)i] : 0u;
+        GridFlags f[V];
+        uint32_t lastk = 0, lastr = 0, tied = 0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const uint32_t j = j0 + (uint32_t)i;
+            f[i] = grid_flags(q[i], q[i + 1], q[i + 2], j, m, b2, false);
+            if (j < m) {
+                if (f[i].khead) lastk = j + 1u;
+                if (f[i].rhead) lastr = j + 1u;
+                tied += f[i].single ? 0u : 1u;
+            }
+        }
+        uint32_t tk, tr, tn;
+        uint32_t curk = block_exclusive_max<NT>(lastk, sh.wsum, tk);
+        uint32_t curr = block_exclusive_max<NT>(lastr, sh.wsum, tr);
+        uint32_t slot = block_exclusive_scan<NT>(tied, sh.wsum, tn);  // (the barriers inside: all of sh.id is read by now)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const uint32_t j = j0 + (uint32_t)i;
+            if (j < m) {
+                if (f[i].khead) curk = j + 1u;
+                if (f[i].rhead) curr = j + 1u;
+                const uint32_t nr = (uint32_t)(q[i + 1] >> b2) + (curk - curr);
+                const uint32_t g = gs[i];
+                a.rank[g] = nr;
+                if (f[i].single) {
+                    const GridPos p = grid_pos(a, g);
+                    a.out[nr] = p.off ? a.in[(uint64_t)p.b * a.block_size + p.off - 1u] : (uint8_t)a.delim;
+                } else {
+                    sh.id[slot++] = g;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        m = tn;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+            ids[v] = e < m ? sh.id[e] : 0u;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace bwtgpu

@@ -465,14 +465,23 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     HIP_TRY(hipGetLastError());
     if ((rc = sort(m, bbits + m0 * sbits))) return rc;
     if ((rc = rerank(m, true, &m))) return rc;
+    const bool trace = std::getenv("BWTGPU_TRACE") != nullptr;  // debugging aid: suffixes left after every round
+    if (trace) fprintf(stderr, "bwtgpu grid forward: rows %u, %d symbols of %d bits first, %u tied\n", a.rows, m0, sbits, m);
     uint64_t h = (uint64_t)m0;
     for (int round = 0; m; ++round) {
         if (round >= 64 || m > a.rows) return fail(BWTGPU_ERR_INTERNAL, "device-wide suffix sort did not converge");
+        if (m <= kGridFinishCap) {  // few left: one workgroup runs the remaining rounds by itself
+            hipLaunchKernelGGL(grid_finish_kernel, dim3(1), dim3(kGridFinishThreads), 0, s, a, id[cur], m, h, (uint32_t)b1,
+                               (uint32_t)b2);
+            HIP_TRY(hipGetLastError());
+            break;
+        }
         hipLaunchKernelGGL(grid_keys_kernel, dim3(stream_grid(d, m, kGridThreads * 4)), dim3(kGridThreads), 0, s, a,
                            id[cur], m, h, (uint32_t)b2, key[cur]);
         HIP_TRY(hipGetLastError());
         if ((rc = sort(m, b1 + b2))) return rc;
         if ((rc = rerank(m, false, &m))) return rc;
+        if (trace) fprintf(stderr, "bwtgpu grid forward: depth %llu, %u tied\n", (unsigned long long)(2 * h), m);
         h *= 2;
     }
     return BWTGPU_OK;
