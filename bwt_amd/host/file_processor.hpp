@@ -51,6 +51,7 @@ private:
     bool good_ = false;  // no read has come up short yet
     size_t input_size_ = 0;
     bool regular_ = false;
+    bool out_regular_ = false;
     std::vector<char> scratch_;
     mutable std::mutex mutex_;  // one lock for both streams, as in the reference
 };

@@ -10,6 +10,8 @@
 #ifndef SLAB_RUNNER_HPP
 #define SLAB_RUNNER_HPP
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <iostream>
@@ -135,6 +137,10 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
     const int depth = 2;
     const size_t unit = direction == BWTGPU_FORWARD ? block_size : block_size + 1;
     const size_t slab_blocks = slab_blocks_for(unit, remaining_bytes);
+    // BWT_HOST_TRACE=1: where the calling thread's time goes (seconds), on stderr
+    const bool trace = std::getenv("BWT_HOST_TRACE") != nullptr;
+    double t_acquire = 0, t_read = 0, t_submit = 0, t_wait = 0, t_write = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::vector<PipelineCache::Lease> leases((size_t)ndev);
     std::vector<bwtgpu_pipeline*> pipes((size_t)ndev, nullptr);
     struct InFlight { int dev, slot; };
@@ -146,15 +152,20 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         inflight.pop_front();
         const uint8_t* out = nullptr;
         size_t n = 0;
-        if (bwtgpu_pipeline_collect(pipes[(size_t)f.dev], f.slot, &out, &n) != BWTGPU_OK) {
+        const double t0 = now();
+        const int crc = bwtgpu_pipeline_collect(pipes[(size_t)f.dev], f.slot, &out, &n);
+        t_wait += now() - t0;
+        if (crc != BWTGPU_OK) {
             if (!rc) std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
             rc = 1;
             return;
         }
+        const double t1 = now();
         if (!rc && !processor.write_bytes(reinterpret_cast<const char*>(out), n)) {
             std::cerr << "Error: short write to the output file" << std::endl;
             rc = 1;
         }
+        t_write += now() - t1;
     };
 
     for (size_t k = 0; !rc; ++k) {
@@ -163,8 +174,10 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         if (inflight.size() == (size_t)ndev * (size_t)depth) drain_one();  // frees exactly (dev, slot)
         if (rc) break;
         if (!pipes[(size_t)dev]) {
+            const double t0 = now();
             leases[(size_t)dev] = PipelineCache::instance().acquire(dev, direction, block_size, slab_blocks, depth);
             pipes[(size_t)dev] = leases[(size_t)dev].p;
+            t_acquire += now() - t0;
             if (!pipes[(size_t)dev]) {
                 std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
                 rc = 1;
@@ -173,9 +186,14 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         }
         bwtgpu_pipeline* p = pipes[(size_t)dev];
         const size_t cap = bwtgpu_pipeline_input_capacity(p);
+        const double t0 = now();
         const size_t got = processor.read_bytes(reinterpret_cast<char*>(bwtgpu_pipeline_input(p, slot)), cap);
+        t_read += now() - t0;
         if (got == 0) break;
-        if (bwtgpu_pipeline_submit(p, slot, got, delimiter) != BWTGPU_OK) {
+        const double t1 = now();
+        const int src = bwtgpu_pipeline_submit(p, slot, got, delimiter);
+        t_submit += now() - t1;
+        if (src != BWTGPU_OK) {
             std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
             rc = 1;
             break;
@@ -184,6 +202,9 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         if (got < cap) break;
     }
     while (!inflight.empty()) drain_one();
+    if (trace)
+        std::fprintf(stderr, "bwt host: pipeline %.3f, read %.3f, submit %.3f, wait %.3f, write %.3f s (slabs of %zu blocks)\n",
+                     t_acquire, t_read, t_submit, t_wait, t_write, slab_blocks);
     for (size_t d = 0; d < pipes.size(); ++d) {
         if (rc) bwtgpu_pipeline_destroy(pipes[d]);  // do not reuse a pipeline that reported an error
         else PipelineCache::instance().release(leases[d], (int)d, direction, block_size, depth);
