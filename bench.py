@@ -36,6 +36,9 @@ WORKLOADS = {
     "random-1g-64k": ("random255", 64 * 1024, 1 * GIB, 2, "1 GiB uniform bytes over 0x00-0xFE, 64 KiB blocks (BASELINE configs[1])"),
     "period7-1g-256k": ("period7", 256 * 1024, 1 * GIB, 4, "1 GiB period-7 text, 256 KiB blocks (BASELINE configs[3])"),
     "mixed-4g-1m": ("mixed", 1024 * 1024, 4 * GIB, 5, "4 GiB-per-GPU slice of the mixed corpus, 1 MiB blocks (BASELINE configs[4], sharded)"),
+    # not a BASELINE config: the shape of a single file (few large blocks), which takes the device-wide
+    # forward path and the tiled inverse table build instead of the one-workgroup-per-block kernels
+    "acgt-16m-1m": ("acgt", 1024 * 1024, 16 * MIB, 3, "16 MiB ACGT text, 1 MiB blocks: few large blocks (one file)"),
 }
 DEFAULT_WORKLOAD = "acgt-4g-256k"
 METRIC = "round-trip BWT GB/s at 256KB blocks, 1/8xMI355X; % of HBM roofline"

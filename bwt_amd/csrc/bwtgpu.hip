@@ -727,7 +727,9 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
         hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
-        if (g.split_shift == kMinSplitShift)  // many segments per block: their records go through LDS (seg_cap <= kStitchLdsSegs then)
+        // many segments per block, or few blocks (the chain following is then the whole cost): the
+        // records go through LDS
+        if (g.seg_cap <= kStitchLdsSegs && (g.split_shift == kMinSplitShift || g.nblocks <= (size_t)d.cus))
             hipLaunchKernelGGL(bwt_inverse_stitch_lds_kernel<1024>, dim3((uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus)),
                                dim3(1024), 0, s, a);
         else
