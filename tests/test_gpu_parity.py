@@ -208,3 +208,41 @@ def test_skewed_distributions_and_many_blocks(orc):
         got = api.forward_batch(data, bs, delim)
         assert got == want[1:], (len(data), bs)
         assert api.inverse_batch(got, bs, delim) == data, (len(data), bs)
+
+
+def test_slab_pipeline_entry_points(orc):
+    """The pipeline calls the C++ host layer is built on, driven through ctypes: upload + byte
+    presence, submit from the uploaded bytes, submit with its own upload, inverse, slot reuse."""
+    import ctypes
+
+    L = api.lib()
+    rng = np.random.default_rng(11)
+    bs = 4096
+    data = rng.integers(0, 200, size=10 * bs + 321, dtype=np.uint8)
+    want = orc.forward_buffer(data.tobytes(), bs, 4)
+    fwd = L.bwtgpu_pipeline_create(0, 0, bs, 16, 2)
+    inv = L.bwtgpu_pipeline_create(0, 1, bs, 16, 2)
+    assert fwd and inv
+    try:
+        assert L.bwtgpu_pipeline_input_capacity(fwd) == 16 * bs
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        for slot, staged in [(0, True), (1, False), (0, False)]:
+            ctypes.memmove(L.bwtgpu_pipeline_input(fwd, slot), data.ctypes.data, data.size)
+            if staged:
+                mask = (ctypes.c_uint32 * 8)()
+                assert L.bwtgpu_pipeline_upload_presence(fwd, slot, data.size, mask) == 0
+                present = set(data.tolist())
+                assert [v for v in range(256) if (mask[v >> 5] >> (v & 31)) & 1] == sorted(present)
+                assert L.bwtgpu_lowest_clear_bit(mask) == want[0]
+            assert L.bwtgpu_pipeline_submit(fwd, slot, data.size, want[0]) == 0
+            assert L.bwtgpu_pipeline_collect(fwd, slot, ctypes.byref(out), ctypes.byref(n)) == 0
+            got = ctypes.string_at(out.value, n.value)
+            assert got == want[1:], (slot, staged)
+        ctypes.memmove(L.bwtgpu_pipeline_input(inv, 0), got, len(got))
+        assert L.bwtgpu_pipeline_submit(inv, 0, len(got), want[0]) == 0
+        assert L.bwtgpu_pipeline_submit(inv, 0, len(got), want[0]) != 0  # not collected yet
+        assert L.bwtgpu_pipeline_collect(inv, 0, ctypes.byref(out), ctypes.byref(n)) == 0
+        assert ctypes.string_at(out.value, n.value) == data.tobytes()
+    finally:
+        L.bwtgpu_pipeline_destroy(fwd)
+        L.bwtgpu_pipeline_destroy(inv)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bring-up check of the device-wide forward path: every case runs through both forward paths
-(BWTGPU_FORWARD_PATH=grid / block) and the two results are compared (the block path is the one the parity suite pins to the oracle).  Prints both timings.  (Development
-aid; the parity suite proper is tests/test_gpu_grid.py.)"""
+(BWTGPU_FORWARD_PATH=grid / block) and the two results are compared; prints both timings.  (Development aid: the parity suite, tests/test_gpu_parity.py,
+runs every one of its cases through both paths against the oracle.)"""
 import os
 import sys
 import time
