@@ -26,7 +26,7 @@ ERR_HIP = -5
 ERR_NO_DELIMITER = -6
 ERR_NO_FREE_BYTE = -7
 ERR_INTERNAL = -8
-MAX_BLOCK_SIZE = 2097151
+MAX_BLOCK_SIZE = 1 << 30
 LEN_NO_DELIMITER = 0xFFFFFFFF
 
 # every symbol include/bwtgpu.h declares

@@ -9,7 +9,7 @@
 //                     stop at the first ch == delimiter; else emit ch }, result reversed (:61-62)
 //
 // Kernel 1, bwt_inverse_build_kernel (one workgroup per block): the LF table
-// T[i] = (C[L[i]] + occ[i]) | splitter flag << 23 | L[i] << 24 -- an LDS byte histogram per wave
+// T[i] = (C[L[i]] + occ[i]) | splitter flag << 23 | L[i] << 24 (TableWord) -- an LDS byte histogram per wave
 // chunk, an exclusive scan in (symbol, wave) order, then a stable per-symbol ranking of every
 // position (wave-ballot match, the same primitive as the forward radix passes).  Packing the
 // symbol next to the successor row makes a walk step ONE dependent 4-byte load.
@@ -45,8 +45,34 @@
 namespace bwtgpu {
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
-constexpr uint32_t kRowMask = 0x007FFFFFu;   // successor row (n <= 2^21 < 2^23)
+constexpr uint32_t kRowMask = 0x007FFFFFu;   // successor row in a 32-bit table word (blocks of at most 2^23 rows)
 constexpr uint32_t kSplitFlag = 0x00800000u; // this row starts a segment
+constexpr uint32_t kNarrowMaxRows = 1u << 21;  // longer blocks get 64-bit table words
+constexpr uint32_t kMaxSegments = 1u << 17;    // regular segments per block, at most: longer blocks are cut more coarsely
+
+// One word of the LF table: successor row, "this row starts a segment", the row's byte.  Blocks of
+// up to kNarrowMaxRows rows pack it into 32 bits (one 4-byte load per walk step, twice the rows
+// per cache line); longer blocks -- which only the tiled build handles -- use 64 bits.
+template <typename TW>
+struct TableWord;
+template <>
+struct TableWord<uint32_t> {
+    static __device__ __forceinline__ uint32_t pack(uint32_t row, bool split, uint32_t c) {
+        return row | (split ? kSplitFlag : 0u) | (c << 24);
+    }
+    static __device__ __forceinline__ uint32_t row(uint32_t w) { return w & kRowMask; }
+    static __device__ __forceinline__ bool split(uint32_t w) { return (w & kSplitFlag) != 0u; }
+    static __device__ __forceinline__ uint32_t byte(uint32_t w) { return w >> 24; }
+};
+template <>
+struct TableWord<uint64_t> {
+    static __device__ __forceinline__ uint64_t pack(uint32_t row, bool split, uint32_t c) {
+        return (uint64_t)row | ((uint64_t)(split ? 1u : 0u) << 32) | ((uint64_t)c << 40);
+    }
+    static __device__ __forceinline__ uint32_t row(uint64_t w) { return (uint32_t)w; }
+    static __device__ __forceinline__ bool split(uint64_t w) { return ((w >> 32) & 1u) != 0u; }
+    static __device__ __forceinline__ uint32_t byte(uint64_t w) { return (uint32_t)(w >> 40) & 255u; }
+};
 constexpr uint32_t kMinSplitShift = 4;       // rows between regular splitters: 16 or 32 (InvArgs::split_shift),
 constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain when the batch has many blocks
 constexpr uint32_t kMultiMinRowsFew = 1280;  // ... and this is the bound when it has few: the chains are the whole cost then
@@ -67,7 +93,7 @@ struct InvArgs {
     uint32_t seg_cap;     // segment slots per block (regular splitters + 1)
     uint32_t seg_wgs;     // workgroups of kSegThreads lanes that cover one block's segments
     uint32_t multi_min_rows;  // blocks of at least this many rows are cut into segments
-    uint32_t* T;          // nblocks * tstride words
+    void* T;              // nblocks * tstride table words (TableWord: 32 or 64 bits)
     uint32_t* drow;       // per block: delimiter row or kNoRow
     uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
     uint2* seg;           // nblocks * seg_cap: x = bytes the segment produces, y = id of the splitter it runs into
@@ -127,7 +153,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         if (b >= a.nblocks) break;
         const uint32_t n = inv_block_len(a, b);
         const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
-        uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+        uint32_t* __restrict__ T = (uint32_t*)a.T + (uint64_t)b * a.tstride;
 
         for (int i = tid; i < W * 256; i += NT) sh.hist[i] = 0;
         __syncthreads();
@@ -207,8 +233,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
                     compiler_fence();  // every lane has read its offset before the leaders advance it
                     if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
                     compiler_fence();
-                    const uint32_t flag = (split && (image < nreg || k == drow)) ? kSplitFlag : 0u;
-                    if (valid) T[k] = (b0 + rk) | flag | (c << 24);
+                    if (valid) T[k] = TableWord<uint32_t>::pack(b0 + rk, split && (image < nreg || k == drow), c);
                     image += step;
                     image -= image >= n ? n : 0u;
                 }
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_hist_kernel(InvArgs a, In
     }
 }
 
-template <int NT>
+template <int NT, typename TW>
 __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, InvTileArgs ta) {
     constexpr int W = NT / kWave;
     static_assert(NT >= 256, "one thread per symbol in the scan");
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, I
     const uint32_t b = blockIdx.x / ta.tiles_per_block, t = blockIdx.x % ta.tiles_per_block;
     const uint32_t n = inv_block_len(a, b);
     const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
-    uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    TW* __restrict__ T = (TW*)a.T + (uint64_t)b * a.tstride;
     const uint32_t tlo = min(t * ta.tile_rows, n), thi = min(tlo + ta.tile_rows, n);
     for (int i = tid; i < W * 256; i += NT) sh.hist[i] = 0;
     // where the rows of this tile with byte value c go: C[c] + occurrences in the tiles before
@@ -362,8 +387,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, I
                 compiler_fence();  // every lane has read its offset before the leaders advance it
                 if (valid && rk == 0) myoff[c] = b0 + (uint32_t)__popcll(peers);
                 compiler_fence();
-                const uint32_t flag = (split && (image < nreg || k == drow)) ? kSplitFlag : 0u;
-                if (valid) T[k] = (b0 + rk) | flag | (c << 24);
+                if (valid) T[k] = TableWord<TW>::pack(b0 + rk, split && (image < nreg || k == drow), c);
                 image += step;
                 image -= image >= n ? n : 0u;
             }
@@ -445,6 +469,7 @@ struct BackWriter {
 // walking back into the delimiter row.  Output bytes are produced back to front; they are
 // packed in registers and leave as aligned 16-byte stores (a lane-private store per byte
 // would be one scattered write per step).
+template <typename TW>
 __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
     const uint32_t b = blockIdx.x * kWave + threadIdx.x;
     if (b >= a.nblocks) return;
@@ -457,16 +482,16 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
         a.lens[b] = 0xFFFFFFFFu;
         return;
     }
-    const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    const TW* __restrict__ T = (const TW*)a.T + (uint64_t)b * a.tstride;
     uint8_t* const o = a.out + (uint64_t)b * a.block_size;
     BackWriter bw;
     bw.init(o + len);
-    row = T[row] & kRowMask;
+    row = TableWord<TW>::row(T[row]);
     for (uint32_t step = 0; step < n; ++step) {
-        const uint32_t wd = T[row];
-        const uint32_t ch = wd >> 24;
+        const TW wd = T[row];
+        const uint32_t ch = TableWord<TW>::byte(wd);
         if (ch == a.delim || bw.addr == o) break;
-        row = wd & kRowMask;
+        row = TableWord<TW>::row(wd);
         bw.push(ch);
     }
     bw.flush();
@@ -489,6 +514,7 @@ __device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, u
 
 // Walks every segment once: its length, the splitter it runs into, and its bytes -- in walk
 // order, 16 at a time -- into the segment's staging slot (then chained pool chunks).
+template <typename TW>
 __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(InvArgs a) {
     uint32_t b, j;
     if (!segment_of_lane(a, b, j)) return;
@@ -504,18 +530,18 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
         a.seg[sb + j] = make_uint2(0u, j);
         return;
     }
-    const uint32_t* __restrict__ T = a.T + (uint64_t)b * a.tstride;
+    const TW* __restrict__ T = (const TW*)a.T + (uint64_t)b * a.tstride;
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
     uint8_t* buf = a.stage + (sb + j) * a.slot;
     uint32_t prevc = 0;
-    uint32_t row = T[start] & kRowMask;
+    uint32_t row = TableWord<TW>::row(T[start]);
     uint32_t t = 0;  // bytes the segment produces
     uint32_t acc = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     uint32_t stop = start;
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     for (uint32_t step = 0; step < n; ++step) {
-        const uint32_t wd = T[row];
-        const bool at_splitter = (wd & kSplitFlag) != 0u;
+        const TW wd = T[row];
+        const bool at_splitter = TableWord<TW>::split(wd);
         if (at_splitter && row == drow) {  // the delimiter row ends the text and has no byte
             stop = row;
             break;
@@ -528,7 +554,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
             prevc = c;
             buf = a.pool + (pb + c) * a.slot;
         }
-        acc |= (wd >> 24) << (8u * (t & 3u));
+        acc |= TableWord<TW>::byte(wd) << (8u * (t & 3u));
         ++t;
         if ((t & 3u) == 0u) {
             q0 = q1; q1 = q2; q2 = q3; q3 = acc;
@@ -542,7 +568,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
             stop = row;
             break;
         }
-        row = wd & kRowMask;
+        row = TableWord<TW>::row(wd);
     }
     if (t & 15u) {  // flush the partial 16-byte group (the slot has room; bytes past t are never used)
         const uint32_t have = (t & 15u) >> 2;  // complete dwords in the group: q3 newest
@@ -565,7 +591,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
 // (short independent chains), one thread then orders the few hundred super nodes, and each
 // thread walks its chain again to hand out the positions.
 constexpr uint32_t kSuperStride = 32;
-constexpr uint32_t kMaxSupers = ((BWTGPU_MAX_BLOCK_SIZE + 1u) >> kMinSplitShift) / kSuperStride + 2u;
+constexpr uint32_t kMaxSupers = kMaxSegments / kSuperStride + 2u;
 
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {

@@ -27,6 +27,7 @@ constexpr size_t kWideMinBlock = 8192; // shorter blocks do not pay for the wide
 constexpr int kFwdThreads = 256;   // forward: threads per workgroup (4 waves, each with an 8 KiB LDS staging tile)
 constexpr int kInvThreads = 256;   // inverse table build: threads per workgroup
 constexpr size_t kHeaderBytes = 256;  // workspace header: work queue + status words
+constexpr size_t kBlockKernelMaxBlock = 2097151;  // forward: blocks above this only take the device-wide path
 constexpr size_t kInvTiledMaxBlocks = 128;   // inverse: batches of at most this many blocks ...
 constexpr size_t kInvTiledMinRows = 16384;   // ... of at least this many rows build their LF tables tile by tile
 
@@ -156,6 +157,15 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     FwdGeom g;
     g.nblocks = (total_len + block_size - 1) / block_size;
     const size_t longest = std::min(total_len, block_size);
+    if (block_size > kBlockKernelMaxBlock) {  // only the device-wide path sorts blocks this long
+        g.ncap = 0;
+        g.stride = 0;
+        g.grid = 0;
+        g.wide = false;
+        g.grid_path = total_len + g.nblocks <= kGridMaxRows;
+        g.bytes = grid_geom(total_len, block_size).bytes;
+        return g;
+    }
     g.ncap = (uint32_t)round_up(longest + 1, 64);
     g.stride = round_up((size_t)g.ncap * 20 + bwtgpu::kBucketDirBytes, 256);
     const size_t max_wgs = (size_t)d.cus * (size_t)d.fwd_wgs_per_cu;
@@ -182,6 +192,7 @@ struct InvGeom {
     uint32_t seg_cap, seg_wgs, chunk_cap, split_shift, slot, multi_min_rows;
     bool split;  // blocks are long enough for the segmented walk
     bool tiled;  // few large blocks: the LF tables are built by many workgroups per block
+    bool wide;   // blocks of more than kNarrowMaxRows rows: 64-bit table words
     uint32_t tile_rows, tiles_per_block;
     size_t dacc_off, thist_off;
     size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
@@ -231,13 +242,17 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.split_shift = kMinSplitShift;
     if (longest < (size_t)192 << 10 || regular_splitters((uint32_t)longest, kMinSplitShift) + 1u > kStitchLdsSegs)
         g.split_shift = kMinSplitShift + 1u;
+    // long blocks: no more segments than the stitch kernels hold super nodes for (and 64 K lanes
+    // per block fill the chip anyway)
+    while (regular_splitters((uint32_t)longest, g.split_shift) > kMaxSegments) ++g.split_shift;
+    g.wide = longest > kNarrowMaxRows;
     g.slot = 4u << g.split_shift;
     g.seg_cap = g.split ? regular_splitters((uint32_t)longest, g.split_shift) + 1u : 1u;
     g.seg_wgs = (g.seg_cap + kSegThreads - 1) / kSegThreads;
     g.chunk_cap = g.split ? (uint32_t)(longest / g.slot) + 8u : 1u;
     // One workgroup builds a 1 MiB block's table in about 2 ms; with fewer blocks than compute
     // units the tables are built tile by tile instead.
-    g.tiled = g.nblocks <= kInvTiledMaxBlocks && longest >= kInvTiledMinRows;
+    g.tiled = g.wide || (g.nblocks <= kInvTiledMaxBlocks && longest >= kInvTiledMinRows);
     g.tile_rows = (uint32_t)round_up(std::max<size_t>(4096, (longest + 255) / 256), 256);
     g.tiles_per_block = (uint32_t)((longest + g.tile_rows - 1) / g.tile_rows);
     size_t off = kHeaderBytes;
@@ -257,7 +272,7 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.next_off = take(g.nblocks * (size_t)g.chunk_cap * 4);
     g.stage_off = take(g.split ? g.nblocks * (size_t)g.seg_cap * g.slot : 0);
     g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * g.slot : 0);
-    g.t_off = take((size_t)g.tstride * 4 * g.nblocks);
+    g.t_off = take((size_t)g.tstride * (g.wide ? 8 : 4) * g.nblocks);
     g.bytes = off;
     return g;
 }
@@ -638,6 +653,9 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     a.ws_stride = g.stride;
     a.queue = (uint32_t*)d_workspace;
     if (g.grid_path) return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
+    if (block_size > kBlockKernelMaxBlock)
+        return fail(BWTGPU_ERR_INVALID, "a batch of blocks above %zu bytes may hold at most 2^31 bytes (%zu given): split it",
+                    kBlockKernelMaxBlock, total_len);
     if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
         const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
@@ -686,7 +704,7 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         splitter_map((uint32_t)std::min(total, unit), &a.split_mul[0], &a.split_inv[0]);
         splitter_map((uint32_t)(total - (g.nblocks - 1) * unit), &a.split_mul[1], &a.split_inv[1]);
     }
-    a.T = (uint32_t*)(ws + g.t_off);
+    a.T = ws + g.t_off;
     a.drow = (uint32_t*)(ws + g.drow_off);
     a.mode = (uint32_t*)(ws + g.mode_off);
     a.seg = (uint2*)(ws + g.seg_off);
@@ -714,18 +732,23 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         ta.dacc = (uint32_t*)(ws + g.dacc_off);
         const uint32_t tiles = (uint32_t)(g.nblocks * g.tiles_per_block);
         hipLaunchKernelGGL(bwt_inverse_tile_hist_kernel<kInvThreads>, dim3(tiles), dim3(kInvThreads), 0, s, a, ta);
-        hipLaunchKernelGGL(bwt_inverse_tile_build_kernel<kInvThreads>, dim3(tiles), dim3(kInvThreads), 0, s, a, ta);
+        if (g.wide)
+            hipLaunchKernelGGL((bwt_inverse_tile_build_kernel<kInvThreads, uint64_t>), dim3(tiles), dim3(kInvThreads), 0, s, a, ta);
+        else
+            hipLaunchKernelGGL((bwt_inverse_tile_build_kernel<kInvThreads, uint32_t>), dim3(tiles), dim3(kInvThreads), 0, s, a, ta);
     } else {
         hipLaunchKernelGGL(bwt_inverse_build_kernel<kInvThreads>, dim3(g.build_grid), dim3(kInvThreads), 0, s, a);
     }
     HIP_TRY(hipGetLastError());
     const uint32_t per_block_grid = (uint32_t)((g.nblocks + kWave - 1) / kWave);
-    hipLaunchKernelGGL(bwt_inverse_walk_kernel, dim3(per_block_grid), dim3(kWave), 0, s, a);
+    if (g.wide) hipLaunchKernelGGL(bwt_inverse_walk_kernel<uint64_t>, dim3(per_block_grid), dim3(kWave), 0, s, a);
+    else hipLaunchKernelGGL(bwt_inverse_walk_kernel<uint32_t>, dim3(per_block_grid), dim3(kWave), 0, s, a);
     HIP_TRY(hipGetLastError());
     if (g.split) {
         const uint64_t wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * g.seg_wgs;
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
-        hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
+        if (g.wide) hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint64_t>, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
+        else hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint32_t>, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
         // many segments per block, or few blocks (the chain following is then the whole cost): the
         // records go through LDS

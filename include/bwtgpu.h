@@ -47,8 +47,10 @@ extern "C" {
 #define BWTGPU_ERR_NO_FREE_BYTE (-7)   /* all 256 byte values occur: no delimiter can be chosen */
 #define BWTGPU_ERR_INTERNAL (-8)       /* a kernel reported an inconsistent state */
 
-/* Largest supported block_size: block + delimiter must fit 21-bit suffix indices. */
-#define BWTGPU_MAX_BLOCK_SIZE ((size_t)2097151)
+/* Largest supported block_size.  Blocks of up to 2 MiB - 1 have dedicated kernels (21-bit suffix
+ * indices, three fields per 64-bit sort key); longer ones always take the device-wide forward
+ * path and 64-bit inverse table words, and one "_device" call may then hold at most 2^31 bytes. */
+#define BWTGPU_MAX_BLOCK_SIZE ((size_t)1 << 30)
 
 /* Value stored in the inverse's per-block length array for a block without delimiter. */
 #define BWTGPU_LEN_NO_DELIMITER 0xFFFFFFFFu

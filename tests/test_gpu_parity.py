@@ -210,6 +210,33 @@ def test_skewed_distributions_and_many_blocks(orc):
         assert api.inverse_batch(got, bs, delim) == data, (len(data), bs)
 
 
+def test_blocks_above_two_mib(orc, forward_path):
+    """Blocks too long for the one-workgroup kernels: device-wide forward path, 64-bit inverse
+    table words, coarser segments.  Against the oracle at 3 and 5 MiB, by round trip at 48 MiB."""
+    if forward_path != "auto":
+        pytest.skip("long blocks have one route")
+    cases = [("random255", 3 << 20, (3 << 20) + 4567), ("acgt", 3 << 20, (3 << 20) + 4567),
+             ("period7", 2500000, 2500000), ("acgt", 5 << 20, 2 * (5 << 20) + 99)]
+    for kind, bs, total in cases:
+        data = synth.generate(kind, synth.base_seed(3), 11, total).tobytes()
+        want = orc.forward_buffer(data, bs, 8)
+        delim = want[0]
+        got = api.forward_batch(data, bs, delim)
+        assert got == want[1:], (kind, bs)
+        assert api.inverse_batch(got, bs, delim) == data, (kind, bs)
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    data = (text * (48 * (1 << 20) // len(text) + 1))[:48 << 20]  # tiled text: long repeats
+    delim = api.find_unused_byte(data)
+    got = api.forward_batch(data, len(data), delim)
+    assert len(got) == len(data) + 1 and got.count(bytes([delim])) == 1
+    assert sorted(np.bincount(np.frombuffer(got, np.uint8), minlength=256).tolist()) == \
+        sorted((np.bincount(np.frombuffer(data, np.uint8), minlength=256) + np.eye(256, dtype=np.int64)[delim]).astype(np.int64).tolist())
+    assert api.inverse_batch(got, len(data), delim) == data
+    with pytest.raises(api.BwtGpuError) as e:
+        api.forward_batch(b"abc", api.MAX_BLOCK_SIZE + 1, 0)
+    assert e.value.code == api.ERR_BLOCK_TOO_LARGE
+
+
 def test_slab_pipeline_entry_points(orc):
     """The pipeline calls the C++ host layer is built on, driven through ctypes: upload + byte
     presence, submit from the uploaded bytes, submit with its own upload, inverse, slot reuse."""
