@@ -162,8 +162,6 @@ def bwt_forward(input, delimiter=b"~") -> bytes:
     d = _delim(delimiter)
     if a.size == 0:
         return bytes([d])
-    if a.size > MAX_BLOCK_SIZE:
-        raise BwtGpuError(ERR_BLOCK_TOO_LARGE, "input longer than the largest supported block")
     return forward_batch(a, a.size, d)
 
 

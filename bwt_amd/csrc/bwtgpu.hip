@@ -93,6 +93,16 @@ int grow(void** p, size_t* cap, size_t need) {
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// A batch shorter than one block IS one block of its own length: block i lies at i * block_size
+// whatever block_size is, and nothing else depends on it.  Shrinking block_size to the batch
+// keeps any value the reference accepts (src/bwt.cpp:251 takes any positive number) usable.
+size_t forward_block_size(size_t total_len, size_t block_size) {
+    return std::min(block_size, std::max<size_t>(total_len, 1));
+}
+size_t inverse_block_size(size_t total_with_delims, size_t block_size) {
+    return std::min(block_size, std::max<size_t>(total_with_delims, 2) - 1);
+}
+
 // ---- forward launch geometry ----------------------------------------------
 struct FwdGeom {
     size_t nblocks;
@@ -613,11 +623,13 @@ size_t bwtgpu_forward_output_bytes(size_t total_len, size_t block_size) {
 }
 
 size_t bwtgpu_forward_workspace_bytes(int device, size_t total_len, size_t block_size) {
+    if (block_size) block_size = forward_block_size(total_len, block_size);
     if (check_device(device) != BWTGPU_OK || block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE) return 0;
     return fwd_geom(*g_dev[device], total_len, block_size).bytes;
 }
 
 size_t bwtgpu_inverse_workspace_bytes(int device, size_t total, size_t block_size) {
+    if (block_size) block_size = inverse_block_size(total, block_size);
     if (check_device(device) != BWTGPU_OK || block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE) return 0;
     return inv_geom(*g_dev[device], total, block_size).bytes;
 }
@@ -628,6 +640,7 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     int rc = check_device(device);
     if (rc) return rc;
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    block_size = forward_block_size(total_len, block_size);
     if (block_size > BWTGPU_MAX_BLOCK_SIZE)
         return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
                     (size_t)BWTGPU_MAX_BLOCK_SIZE);
@@ -672,6 +685,7 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     int rc = check_device(device);
     if (rc) return rc;
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    block_size = inverse_block_size(total, block_size);
     if (block_size > BWTGPU_MAX_BLOCK_SIZE)
         return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
                     (size_t)BWTGPU_MAX_BLOCK_SIZE);
@@ -769,6 +783,7 @@ int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t
     int rc = check_device(device);
     if (rc) return rc;
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    block_size = forward_block_size(total_len, block_size);
     if (block_size > BWTGPU_MAX_BLOCK_SIZE)
         return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
                     (size_t)BWTGPU_MAX_BLOCK_SIZE);
@@ -807,6 +822,7 @@ int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total, size_t blo
     int rc = check_device(device);
     if (rc) return rc;
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    block_size = inverse_block_size(total, block_size);
     if (block_size > BWTGPU_MAX_BLOCK_SIZE)
         return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
                     (size_t)BWTGPU_MAX_BLOCK_SIZE);

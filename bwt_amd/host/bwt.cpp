@@ -117,6 +117,13 @@ static int forward_single_slab(const char* input_file, const char* output_file, 
 }
 
 int bwt_forward_process_file(const char* input_file, const char* output_file, size_t block_size) {
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE) {
+        // A block size beyond the file makes the file one block of its own length; only a file
+        // that really has to be cut into blocks longer than the library's limit is refused (later).
+        FileProcessor probe(input_file, "", 1);
+        if (probe.is_open() && probe.input_is_regular() && probe.input_size() < block_size)
+            block_size = probe.input_size() ? probe.input_size() : 1;
+    }
     const int fast = forward_single_slab(input_file, output_file, block_size);
     if (fast >= 0) return fast;
     const int delimiter_byte = find_unique_char(input_file);

@@ -42,6 +42,9 @@ int bwt_inverse_process_file(const char* input_file, const char* output_file, si
         return 1;
     }
     const size_t body = processor.input_size() ? processor.input_size() - 1 : 0;
+    // a block size beyond the file: the body is one chunk of its own length
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE && processor.input_is_regular() && body >= 1 && body - 1 < block_size)
+        block_size = body > 1 ? body - 1 : 1;
     const int rc = bwt_host::run_slabs(processor, BWTGPU_INVERSE, block_size, static_cast<unsigned char>(delimiter), body);
     processor.close();
     return rc;

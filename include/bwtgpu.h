@@ -51,6 +51,9 @@ extern "C" {
  * indices, three fields per 64-bit sort key); longer ones always take the device-wide forward
  * path and 64-bit inverse table words, and one "_device" call may then hold at most 2^31 bytes. */
 #define BWTGPU_MAX_BLOCK_SIZE ((size_t)1 << 30)
+/* A batch no longer than one block is one block of its own length, so for such a batch any
+ * block_size is accepted (the reference takes any positive value, src/bwt.cpp:251); the limit
+ * applies to batches that really are cut into blocks longer than it. */
 
 /* Value stored in the inverse's per-block length array for a block without delimiter. */
 #define BWTGPU_LEN_NO_DELIMITER 0xFFFFFFFFu

@@ -71,6 +71,13 @@ def test_cli_contract(tmp_path):
     assert os.path.getsize(f) == n + 1 + (n + 127) // 128
     assert run([inv, f, b]).returncode == 0
     assert open(b, "rb").read() == open(src, "rb").read()
+    # any block size the reference accepts works: beyond the file it means "one block"
+    f2, b2 = str(tmp_path / "g2.bwt"), str(tmp_path / "g2.out")
+    assert run([bwt, src, f, "1048576"]).returncode == 0
+    assert run([bwt, src, f2, "5000000000"]).returncode == 0
+    assert open(f2, "rb").read() == open(f, "rb").read()
+    assert run([inv, f2, b2, "5000000000"]).returncode == 0
+    assert open(b2, "rb").read() == open(src, "rb").read()
     # empty file -> 1-byte output (delimiter 0x00); inverting it gives an empty file
     e, ef, eb = str(tmp_path / "e"), str(tmp_path / "e.bwt"), str(tmp_path / "e.out")
     open(e, "wb").close()
