@@ -80,7 +80,7 @@ constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition a
 // sweep (when not fused), 4 later key builds, 5 later sorts, 6 later reranks, 7 full-rank
 // rebuilds, 8 blocks, 9 later rounds, 10 round-0 rerank of buckets in LDS (or their plain
 // write-back), 11 round-0 bucket sorts through HBM, 12 round-0 bucket sorts in LDS, 13 / 14 later
-// rounds' chunk sorts / chunk reranks in LDS.
+// rounds' chunk sorts / chunk reranks in LDS, 15 periodic-run resolution.
 struct PhaseClock {
     unsigned long long t;
     unsigned long long* acc;
@@ -1268,6 +1268,209 @@ __device__ __forceinline__ void rerank_chunk(uint32_t cnt, uint64_t* __restrict_
     __syncthreads();  // the counters, the ballots and the LDS chunk are free again
 }
 
+// ---- periodic runs: whole groups resolved in one step ---------------------------------------------
+// A group of suffixes tied over their first h symbols whose positions form an arithmetic
+// progression i, i+p, i+2p, ... with p <= h lies inside a stretch of the text with period p (each
+// member's h symbols overlap the next member's), and two neighbours i+ap, i+(a+1)p agree exactly
+// up to the position E where that period breaks -- the SAME E for every pair.  So the comparison
+// of text[E-p] with text[E] (the end of the block counting as lowest, src/bwt.cpp:77-79) orders
+// all of them at once: ascending position if text[E-p] < text[E], descending otherwise.  Plain
+// doubling needs log2(run length / h) more rounds for such a group, each sorting all of it --
+// period-7 text in 256 KiB blocks: 15 rounds through HBM in which almost nothing splits.
+//
+// Works on the survivor list `list` (m elements, group << gshift | index, sorted by group; rank[]
+// of a member = row of its group's first suffix): per-group minimum, maximum and count of the
+// positions (table at the end of `spare`), the groups that are such progressions get their final
+// ranks and output bytes, the others are copied to the front of `spare` in order.  Returns the
+// number of suffixes left (== m: nothing was resolved and `list` is still the list; else the
+// list is now in `spare`).
+constexpr uint32_t kMaxPeriod = 256;  // the break of the period is searched by one lane per group
+constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u;
+
+template <int NT>
+__device__ __forceinline__ uint32_t resolve_periodic_groups(const uint64_t* __restrict__ list, uint64_t* spare,
+                                                            uint32_t ncap, uint32_t m, uint32_t G, uint32_t h,
+                                                            uint32_t* __restrict__ rank, const BlockIO& io, int ibits,
+                                                            int gshift, FwdShared<NT>& sh) {
+    constexpr int W = NT / kWave;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    if ((uint64_t)m + 2ull * G > (uint64_t)ncap) return m;  // no room for the table: workgroup-uniform
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(spare + (ncap - 2u * G));  // per group: min, max, count, state
+    const uint64_t imask = (1ull << ibits) - 1ull;
+    const uint32_t n = io.n, len = io.n - 1u;
+    for (uint32_t g = tid; g < G; g += NT) {
+        tbl[4u * g + 0u] = 0xFFFFFFFFu;
+        tbl[4u * g + 1u] = 0u;
+        tbl[4u * g + 2u] = 0u;
+        tbl[4u * g + 3u] = 0u;
+    }
+    if (tid == 0) sh.chunk_bad = 0;
+    __syncthreads();
+    Chunking ck;
+    ck.init(m, W);
+    const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, m);
+    // 1. minimum, maximum, count per group (a vector that lies inside one group: one update)
+    constexpr int U = 4;  // vectors whose loads are issued together
+#pragma unroll 1
+    for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+        uint64_t es[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) es[u] = list[min(base0 + (uint32_t)(u * kWave + lane), m - 1u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t base = base0 + (uint32_t)(u * kWave);
+            if (base >= hi) break;  // wave-uniform
+            const bool valid = base + lane < hi;
+            const uint32_t g = (uint32_t)(es[u] >> gshift), idx = (uint32_t)(es[u] & imask);
+            const uint32_t g0 = __shfl(g, 0);
+            if (__ballot(valid && g != g0) == 0ull) {
+                uint32_t mn = valid ? idx : 0xFFFFFFFFu, mx = valid ? idx : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+                    mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+                }
+                const uint32_t members = (uint32_t)__popcll(__ballot(valid));
+                if (lane == 0) {
+                    atomicMin(&tbl[4u * g0 + 0u], mn);
+                    atomicMax(&tbl[4u * g0 + 1u], mx);
+                    atomicAdd(&tbl[4u * g0 + 2u], members);
+                }
+            } else if (valid) {
+                atomicMin(&tbl[4u * g + 0u], idx);
+                atomicMax(&tbl[4u * g + 1u], idx);
+                atomicAdd(&tbl[4u * g + 2u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // 2. candidates: count - 1 equal steps of p <= h between minimum and maximum, all h symbols inside the block
+    for (uint32_t g = tid; g < G; g += NT) {
+        const uint32_t mn = tbl[4u * g + 0u], mx = tbl[4u * g + 1u], cnt = tbl[4u * g + 2u];
+        uint32_t state = 0;
+        if (cnt >= 2u && (uint64_t)mx + h <= (uint64_t)len) {
+            const uint32_t span = mx - mn, per = span / (cnt - 1u);
+            if (per * (cnt - 1u) == span && per >= 1u && per <= h && per <= kMaxPeriod) state = kPeriodGood | per;
+        }
+        tbl[4u * g + 3u] = state;
+    }
+    __syncthreads();
+    // 3. every member on the progression?  (count distinct positions, all congruent, within the span: then it is the progression)
+#pragma unroll 1
+    for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+        uint64_t es[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) es[u] = list[min(base0 + (uint32_t)(u * kWave + lane), m - 1u)];
+        uint32_t st[U], mn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = (uint32_t)(es[u] >> gshift);
+            st[u] = tbl[4u * g + 3u];
+            mn[u] = tbl[4u * g + 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t k = base0 + (uint32_t)(u * kWave + lane);
+            const uint32_t g = (uint32_t)(es[u] >> gshift), idx = (uint32_t)(es[u] & imask);
+            if (k < hi && (st[u] & kPeriodGood) && (idx - mn[u]) % (st[u] & 0xFFFFu) != 0u) tbl[4u * g + 3u] = 0u;
+        }
+    }
+    __syncthreads();
+    // 4. where the period breaks, and which way that orders the group
+    auto symbol = [&](uint32_t x) { return x < len ? (int)io.s[x] : (x == len ? (int)io.delim : -1); };
+    for (uint32_t g = tid; g < G; g += NT) {
+        const uint32_t state = tbl[4u * g + 3u];
+        if (!(state & kPeriodGood)) continue;
+        const uint32_t per = state & 0xFFFFu, from = tbl[4u * g + 1u] + h;
+        uint32_t found = 0, asc = 0;
+        for (uint32_t t = 0; t <= per; ++t) {  // the break lies within one period of `from`, or the group would have another member
+            const uint32_t x = from + t;
+            const int a = symbol(x - per), b = symbol(x);
+            if (a != b) {
+                found = 1;
+                asc = a < b ? 1u : 0u;
+                break;
+            }
+            if (x >= n) break;
+        }
+        if (found) {
+            tbl[4u * g + 3u] = state | (asc ? kPeriodAsc : 0u);
+            atomicAdd(&sh.chunk_bad, tbl[4u * g + 2u]);
+        } else {
+            tbl[4u * g + 3u] = 0u;
+        }
+    }
+    __syncthreads();
+    const uint32_t resolved = sh.chunk_bad;
+    __syncthreads();
+    if (resolved == 0) return m;
+    // 5. final ranks and output bytes for the resolved groups, the others move on in order.
+    // With few groups the resolved ones are written out member by member in position order
+    // (member a of a group sits at min + a p and goes to row first + a or first + count - 1 - a:
+    // consecutive rows, evenly strided text and rank accesses) rather than in list order.
+    const bool by_group = G <= 64u;
+    const bool later = resolved < m;  // suffixes remain: their next keys will look these ranks up
+    if (by_group) {
+#pragma unroll 1
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t state = tbl[4u * g + 3u];
+            if (!(state & kPeriodGood)) continue;  // workgroup-uniform
+            const uint32_t mn = tbl[4u * g + 0u], cnt = tbl[4u * g + 2u], per = state & 0xFFFFu;
+            const uint32_t first = rank[mn];
+            __syncthreads();  // every thread has the group's first row before any member's rank changes
+            for (uint32_t a = tid; a < cnt; a += NT) {
+                const uint32_t idx = mn + a * per;
+                const uint32_t r = first + ((state & kPeriodAsc) ? a : cnt - 1u - a);
+                if (later) rank[idx] = r;
+                if (r < n) io.out[r] = idx ? io.s[idx - 1u] : (uint8_t)io.delim;
+            }
+        }
+    }
+    if (by_group && !later) {  // nothing to carry on
+        __syncthreads();
+        return 0;
+    }
+    {
+        uint32_t kept = 0;
+#pragma unroll 1
+        for (uint32_t base = lo; base < hi; base += kWave) {
+            const uint32_t k = base + lane;
+            const bool keep = k < hi && !(tbl[4u * (uint32_t)(list[k] >> gshift) + 3u] & kPeriodGood);
+            kept += (uint32_t)__popcll(__ballot(keep));
+        }
+        if (lane == 0) sh.cntA[w] = kept;
+    }
+    __syncthreads();
+    uint32_t pos = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+        if (i < w) pos += sh.cntA[i];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll 1
+    for (uint32_t base = lo; base < hi; base += kWave) {
+        const uint32_t k = base + lane;
+        const bool valid = k < hi;
+        const uint64_t e = list[valid ? k : base];
+        const uint32_t g = (uint32_t)(e >> gshift), idx = (uint32_t)(e & imask);
+        const uint32_t state = tbl[4u * g + 3u];
+        const bool good = valid && (state & kPeriodGood);
+        const uint64_t K = __ballot(valid && !good);
+        if (good) {
+            if (!by_group) {
+                const uint32_t a = (idx - tbl[4u * g + 0u]) / (state & 0xFFFFu), cnt = tbl[4u * g + 2u];
+                const uint32_t r = rank[idx] + ((state & kPeriodAsc) ? a : cnt - 1u - a);
+                if (later) rank[idx] = r;
+                if (r < n) io.out[r] = idx ? io.s[idx - 1u] : (uint8_t)io.delim;
+            }
+        } else if (valid) {
+            spare[pos + (uint32_t)__popcll(K & lt)] = e;
+        }
+        pos += (uint32_t)__popcll(K);
+    }
+    __syncthreads();
+    return m - resolved;
+}
+
 template <int NT>
 __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
                                               uint8_t* __restrict__ out, uint64_t* bufA, uint64_t* bufB,
@@ -1425,7 +1628,22 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);
         } else {
-            sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
+            // too long for LDS: through HBM -- unless all its keys are equal (periodic text: a handful
+            // of keys in all), which one read finds out
+            if (tid == 0) sh.chunk_bad = 0;
+            __syncthreads();
+            {
+                const uint64_t* __restrict__ bk = sorted0 + s0;
+                const uint64_t k0 = bk[0] >> kshift0;
+                bool differs = false;
+                for (uint32_t i = tid; i < cnt; i += NT) differs = differs || (bk[i] >> kshift0) != k0;
+                const uint64_t any = __ballot(differs);
+                if (any && lane == 0) sh.chunk_bad = 1;
+            }
+            __syncthreads();
+            const bool constant = sh.chunk_bad == 0;
+            __syncthreads();
+            if (!constant) sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
             pc.lap(11);
         }
     }
@@ -1484,7 +1702,19 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         DigitPlan plan;
         plan.init(rbits + gbits);
         // small groups: the round runs chunk by chunk inside LDS (the bucket directory's slots hold the cuts)
-        const uint32_t nchunks = cut_chunks<NT>(alt, m, gshift, (uint32_t)FwdShared<NT>::kSortCap, dir.start, sh);
+        uint32_t nchunks = cut_chunks<NT>(alt, m, gshift, (uint32_t)FwdShared<NT>::kSortCap, dir.start, sh);
+        if (full && nchunks == 0) {  // long groups: the ones that are periodic runs are settled at once
+            const uint32_t left = resolve_periodic_groups<NT>(alt, cur, a.ncap, m, G, h, rank, io, ibits, gshift, sh);
+            pc.lap(15);
+            if (left != m) {
+                uint64_t* t = alt;
+                alt = cur;
+                cur = t;
+                m = left;
+                if (m == 0) break;
+                nchunks = cut_chunks<NT>(alt, m, gshift, (uint32_t)FwdShared<NT>::kSortCap, dir.start, sh);
+            }
+        }
         zero_hist<NT>(sh, 0);
         __syncthreads();
         {
