@@ -213,6 +213,38 @@ def test_skewed_distributions_and_many_blocks(orc):
         assert api.inverse_batch(got, bs, delim) == data, (len(data), bs)
 
 
+def test_periodic_runs(orc):
+    """Long groups whose positions form an arithmetic progression are ordered in one step by the
+    batch kernel: both directions, several periods in one block, periods that only qualify in a
+    later round, more than 64 such groups at once, a delimiter that continues the period."""
+    rng = np.random.default_rng(2024)
+    unit100 = rng.integers(0, 256, size=100, dtype=np.uint8)
+    unit100[unit100 == 255] = 7
+    cases = [
+        (np.tile(np.frombuffer(b"abcdefg", np.uint8), 40000), 280000, None),
+        (np.tile(unit100, 3000), 300000, None),                                  # 100 groups, period > first depth
+        (np.concatenate([np.tile(np.frombuffer(b"ab", np.uint8), 60000), np.frombuffer(b"z", np.uint8),
+                         rng.integers(97, 123, size=30000, dtype=np.uint8),
+                         np.tile(np.frombuffer(b"xyz", np.uint8), 30000), np.zeros(40000, np.uint8),
+                         np.frombuffer(b"q", np.uint8), np.full(50000, 200, np.uint8)]), 1 << 20, None),
+        (np.tile(np.frombuffer(b"ba", np.uint8), 70000), 140000, None),
+        (np.tile(np.frombuffer(b"abc", np.uint8), 300 * 16384 // 3 + 10), 16384, None),  # more blocks than CUs: 256-thread kernel
+        (np.full(50000, ord("a"), np.uint8), 50000, ord("a")),                   # the delimiter continues the run
+        (np.tile(np.frombuffer(b"abc", np.uint8), 30000), 90000, ord("a")),
+    ]
+    for arr, bs, delim in cases:
+        data = arr.tobytes()
+        if delim is None:
+            want = orc.forward_buffer(data, bs, 8)
+            delim, want = want[0], want[1:]
+        else:
+            want = orc.forward(data, delim)
+        got = api.forward_batch(data, bs, delim)
+        assert got == want, (len(data), bs, delim)
+        if data.count(bytes([delim])) == 0:
+            assert api.inverse_batch(got, bs, delim) == data
+
+
 def test_blocks_above_two_mib(orc, forward_path):
     """Blocks too long for the one-workgroup kernels: device-wide forward path, 64-bit inverse
     table words, coarser segments.  Against the oracle at 3 and 5 MiB, by round trip at 48 MiB."""
