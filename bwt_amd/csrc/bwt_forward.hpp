@@ -483,6 +483,115 @@ __device__ __forceinline__ void sort_range_global(uint64_t* a, uint64_t* b, uint
     __syncthreads();
 }
 
+// ---- a range in which one key dominates -----------------------------------------------------------
+// Periodic text and long runs give round-0 buckets that hold ONE key tens of thousands of times
+// plus a handful of others (the suffixes near the block's end).  Radix-sorting such a bucket
+// through HBM moves all of it four times over to put those few in place.  Instead: the dominant
+// key is guessed from 64 samples; one sweep counts the elements below / above it; if they are
+// few (<= kAsideCap) a second sweep lifts them out into LDS together with the dominant-key
+// elements that sit where they belong (the first n_lt and the last n_gt slots), and then those
+// fill the holes left in the middle while the others, ranked among themselves, take the two ends.
+// Elements with equal keys may stand in any order (they are one group for the rerank).  Returns
+// false, leaving the range untouched, when no key dominates like that.
+constexpr uint32_t kAsideCap = 1024;
+
+template <int NT>
+__device__ __noinline__ bool settle_dominant_key(uint64_t* __restrict__ a, uint32_t cnt, int kshift,
+                                                    FwdShared<NT>& sh) {
+    constexpr int W = NT / kWave;
+    static_assert(FwdShared<NT>::kSortCap >= 3 * (int)kAsideCap, "three lists of kAsideCap words in the sort buffer");
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    uint64_t* s_ne = sh.u.lsort;                     // the elements whose key is not the dominant one
+    uint64_t* s_mv = sh.u.lsort + kAsideCap;         // dominant-key elements that stand in the two end regions
+    uint32_t* s_pos = reinterpret_cast<uint32_t*>(sh.u.lsort + 2 * kAsideCap);  // where s_ne[i] stood
+    uint32_t* s_hole = s_pos + kAsideCap;            // slots in the middle region that s_ne elements vacate
+    const uint64_t lt = lanemask_lt();
+    // the dominant key: the most frequent among 64 samples
+    if (w == 0) {
+        const uint64_t k = a[(uint32_t)(((uint64_t)lane * cnt) >> 6)] >> kshift;
+        uint32_t same = 0;
+        for (int i = 0; i < kWave; ++i) same += __shfl(k, i) == k ? 1u : 0u;
+        uint32_t best = same;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor(best, o));
+        const uint64_t pick = __ballot(same == best);
+        const uint64_t kd = __shfl(k, __ffsll((unsigned long long)pick) - 1);
+        if (lane == 0) {
+            sh.u.lsort[3 * kAsideCap] = kd;
+            sh.cntA[0] = sh.cntA[1] = sh.cntA[2] = sh.cntA[3] = 0;
+        }
+    }
+    __syncthreads();
+    const uint64_t kd = sh.u.lsort[3 * kAsideCap];
+    // how many below, how many above
+    {
+        uint32_t nl = 0, ng = 0;
+        for (uint32_t i = tid; i < cnt; i += NT) {
+            const uint64_t k = a[i] >> kshift;
+            nl += k < kd ? 1u : 0u;
+            ng += k > kd ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nl += __shfl_xor(nl, o);
+            ng += __shfl_xor(ng, o);
+        }
+        if (lane == 0 && (nl | ng)) {
+            atomicAdd(&sh.cntA[0], nl);
+            atomicAdd(&sh.cntA[1], ng);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_lt = sh.cntA[0], n_gt = sh.cntA[1], n_ne = n_lt + n_gt;
+    __syncthreads();
+    if (n_ne == 0) return true;
+    if (n_ne > kAsideCap) return false;
+    if (tid == 0) sh.cntA[0] = sh.cntA[1] = 0;
+    __syncthreads();
+    // lift the others out, and the dominant-key elements that stand in the end regions
+    const uint32_t mid_hi = cnt - n_gt;
+    for (uint32_t base = 0; base < cnt; base += NT) {
+        const uint32_t q = base + tid;
+        const bool valid = q < cnt;
+        const uint64_t e = valid ? a[q] : 0ull;
+        const bool ne = valid && (e >> kshift) != kd;
+        const bool edge = q < n_lt || q >= mid_hi;
+        const uint64_t NE = __ballot(ne), MV = __ballot(valid && !ne && edge), HO = __ballot(ne && !edge);
+        uint32_t b_ne = 0, b_mv = 0, b_ho = 0;
+        if (lane == 0) {
+            if (NE) b_ne = atomicAdd(&sh.cntA[0], (uint32_t)__popcll(NE));
+            if (MV) b_mv = atomicAdd(&sh.cntA[1], (uint32_t)__popcll(MV));
+            if (HO) b_ho = atomicAdd(&sh.cntA[2], (uint32_t)__popcll(HO));
+        }
+        b_ne = __shfl(b_ne, 0);
+        b_mv = __shfl(b_mv, 0);
+        b_ho = __shfl(b_ho, 0);
+        if (ne) {
+            const uint32_t i = b_ne + (uint32_t)__popcll(NE & lt);
+            s_ne[i] = e;
+            s_pos[i] = q;
+            if (!edge) s_hole[b_ho + (uint32_t)__popcll(HO & lt)] = q;
+        } else if (valid && edge) {
+            s_mv[b_mv + (uint32_t)__popcll(MV & lt)] = e;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_mv = sh.cntA[1];  // == number of holes: the end regions hold n_ne slots, n_ne - holes of them taken by the others
+    // dominant-key elements into the holes; the others, ranked among themselves, to the two ends
+    for (uint32_t i = tid; i < n_mv; i += NT) a[s_hole[i]] = s_mv[i];
+    for (uint32_t i = tid; i < n_ne; i += NT) {
+        const uint64_t e = s_ne[i], k = e >> kshift;
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n_ne; ++j) {
+            const uint64_t kj = s_ne[j] >> kshift;
+            r += (kj < k || (kj == k && j < i)) ? 1u : 0u;
+        }
+        a[r < n_lt ? r : cnt - n_ne + r] = e;
+    }
+    __syncthreads();
+    return true;
+}
+
 // ---- round 0: rolling packed keys -------------------------------------------------------------
 struct Round0 {
     const uint8_t* s;      // block text (len bytes), the delimiter is virtual at position len
@@ -1288,7 +1397,7 @@ constexpr uint32_t kMaxPeriod = 256;  // the break of the period is searched by 
 constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u;
 
 template <int NT>
-__device__ __forceinline__ uint32_t resolve_periodic_groups(const uint64_t* __restrict__ list, uint64_t* spare,
+__device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restrict__ list, uint64_t* spare,
                                                             uint32_t ncap, uint32_t m, uint32_t G, uint32_t h,
                                                             uint32_t* __restrict__ rank, const BlockIO& io, int ibits,
                                                             int gshift, FwdShared<NT>& sh) {
@@ -1628,21 +1737,9 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);
         } else {
-            // too long for LDS: through HBM -- unless all its keys are equal (periodic text: a handful
-            // of keys in all), which one read finds out
-            if (tid == 0) sh.chunk_bad = 0;
-            __syncthreads();
-            {
-                const uint64_t* __restrict__ bk = sorted0 + s0;
-                const uint64_t k0 = bk[0] >> kshift0;
-                bool differs = false;
-                for (uint32_t i = tid; i < cnt; i += NT) differs = differs || (bk[i] >> kshift0) != k0;
-                const uint64_t any = __ballot(differs);
-                if (any && lane == 0) sh.chunk_bad = 1;
-            }
-            __syncthreads();
-            const bool constant = sh.chunk_bad == 0;
-            __syncthreads();
+            // too long for LDS: through HBM -- unless one key makes up nearly all of it (periodic
+            // text, long runs), which takes one read to find out and a few moves to put right
+            const bool constant = settle_dominant_key<NT>(sorted0 + s0, cnt, kshift0, sh);
             if (!constant) sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
             pc.lap(11);
         }
