@@ -127,6 +127,7 @@ struct FwdShared {
     uint32_t wsum[W];
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
     uint32_t chunk_bad;             // a doubling round's survivors cannot be cut into LDS-sized chunks of whole groups
+    unsigned long long vote;        // periodic runs: members << 32 | step of the most populous long step
     uint32_t tailrow[kMaxM0 + 1];   // final rows of the suffixes that reach the delimiter within m0 symbols
     uint32_t blk;
 };
@@ -1377,6 +1378,65 @@ __device__ __forceinline__ void rerank_chunk(uint32_t cnt, uint64_t* __restrict_
     __syncthreads();  // the counters, the ballots and the LDS chunk are free again
 }
 
+// next_break[x] (x in [0, n]) = the first y >= x, y >= P, with text[y] != text[y - P]; the position n
+// (past the block's last symbol, the delimiter) always counts as one.  With it, "the text has period P
+// over [lo, hi)" is next_break[lo + P] >= hi, and the place where a periodic stretch ends is one load.
+template <int NT>
+__device__ __noinline__ void build_next_break(uint32_t* __restrict__ next_break, uint32_t P, const BlockIO& io,
+                                              FwdShared<NT>& sh) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t n = io.n, len = io.n - 1u;
+    auto symbol = [&](uint32_t x) { return x < len ? (int)io.s[x] : (x == len ? (int)io.delim : -1); };
+    auto breaks = [&](uint32_t y) { return y >= P && y <= n && (y == n || symbol(y) != symbol(y - P)); };
+    Chunking ck;
+    ck.init(n + 1u, W);
+    const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, n + 1u);
+    constexpr int U = 4;  // vectors whose loads are issued together
+    uint32_t firstb = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
+        uint64_t F[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t y = base0 + (uint32_t)(u * kWave + lane);
+            F[u] = __ballot(y < hi && breaks(y));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (F[u] && firstb == 0xFFFFFFFFu) firstb = base0 + (uint32_t)(u * kWave) + (uint32_t)__ffsll((unsigned long long)F[u]) - 1u;
+    }
+    if (lane == 0) sh.lastH[w] = firstb;
+    __syncthreads();
+    uint32_t carry = n;
+#pragma unroll
+    for (int i = W - 1; i >= 0; --i)
+        if (i > w && sh.lastH[i] != 0xFFFFFFFFu) carry = sh.lastH[i];  // ends with the nearest later chunk that has one
+    if (lo < hi) {
+        const uint32_t span = U * kWave;
+#pragma unroll 1
+        for (uint32_t base0 = lo + ((hi - lo - 1u) / span) * span;; base0 -= span) {
+            uint64_t F[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t y = base0 + (uint32_t)(u * kWave + lane);
+                F[u] = __ballot(y < hi && breaks(y));
+            }
+#pragma unroll
+            for (int u = U - 1; u >= 0; --u) {
+                const uint32_t base = base0 + (uint32_t)(u * kWave);
+                const uint32_t y = base + lane;
+                const uint64_t at_or_after = F[u] & ~lt;
+                if (y < hi) next_break[y] = at_or_after ? base + (uint32_t)__ffsll((unsigned long long)at_or_after) - 1u : carry;
+                if (F[u]) carry = base + (uint32_t)__ffsll((unsigned long long)F[u]) - 1u;
+            }
+            if (base0 == lo) break;
+        }
+    }
+    __syncthreads();
+}
+
 // ---- periodic runs: whole groups resolved in one step ---------------------------------------------
 // A group of suffixes tied over their first h symbols whose positions form an arithmetic
 // progression i, i+p, i+2p, ... with p <= h lies inside a stretch of the text with period p (each
@@ -1389,12 +1449,13 @@ __device__ __forceinline__ void rerank_chunk(uint32_t cnt, uint64_t* __restrict_
 //
 // Works on the survivor list `list` (m elements, group << gshift | index, sorted by group; rank[]
 // of a member = row of its group's first suffix): per-group minimum, maximum and count of the
-// positions (table at the end of `spare`), the groups that are such progressions get their final
+// positions (a table in LDS, at most kTableGroups groups), the groups that are such progressions get their final
 // ranks and output bytes, the others are copied to the front of `spare` in order.  Returns the
 // number of suffixes left (== m: nothing was resolved and `list` is still the list; else the
 // list is now in `spare`).
 constexpr uint32_t kMaxPeriod = 256;  // the break of the period is searched by one lane per group
-constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u;
+constexpr uint32_t kTableGroups = 2048;  // more groups than this: no table, one thread walks each (short) group
+constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u, kPeriodMask = 0x00FFFFFFu;
 
 template <int NT>
 __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restrict__ list, uint64_t* spare,
@@ -1403,8 +1464,10 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
                                                             int gshift, FwdShared<NT>& sh) {
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    if ((uint64_t)m + 2ull * G > (uint64_t)ncap) return m;  // no room for the table: workgroup-uniform
-    uint32_t* tbl = reinterpret_cast<uint32_t*>(spare + (ncap - 2u * G));  // per group: min, max, count, state
+    static_assert(FwdShared<NT>::kSortCap * 2 >= 4 * (int)kTableGroups, "the group table lives in the LDS sort buffer");
+    if (G > kTableGroups) return m;  // workgroup-uniform
+    (void)ncap;
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(sh.u.lsort);  // per group: min, max, count, state
     const uint64_t imask = (1ull << ibits) - 1ull;
     const uint32_t n = io.n, len = io.n - 1u;
     for (uint32_t g = tid; g < G; g += NT) {
@@ -1453,13 +1516,13 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
         }
     }
     __syncthreads();
-    // 2. candidates: count - 1 equal steps of p <= h between minimum and maximum, all h symbols inside the block
+    // 2. candidates: count - 1 equal steps between minimum and maximum, all h symbols inside the block
     for (uint32_t g = tid; g < G; g += NT) {
         const uint32_t mn = tbl[4u * g + 0u], mx = tbl[4u * g + 1u], cnt = tbl[4u * g + 2u];
         uint32_t state = 0;
         if (cnt >= 2u && (uint64_t)mx + h <= (uint64_t)len) {
             const uint32_t span = mx - mn, per = span / (cnt - 1u);
-            if (per * (cnt - 1u) == span && per >= 1u && per <= h && per <= kMaxPeriod) state = kPeriodGood | per;
+            if (per * (cnt - 1u) == span && per >= 1u) state = kPeriodGood | per;
         }
         tbl[4u * g + 3u] = state;
     }
@@ -1481,28 +1544,47 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
         for (int u = 0; u < U; ++u) {
             const uint32_t k = base0 + (uint32_t)(u * kWave + lane);
             const uint32_t g = (uint32_t)(es[u] >> gshift), idx = (uint32_t)(es[u] & imask);
-            if (k < hi && (st[u] & kPeriodGood) && (idx - mn[u]) % (st[u] & 0xFFFFu) != 0u) tbl[4u * g + 3u] = 0u;
+            if (k < hi && (st[u] & kPeriodGood) && (idx - mn[u]) % (st[u] & kPeriodMask) != 0u) tbl[4u * g + 3u] = 0u;
         }
     }
     __syncthreads();
-    // 4. where the period breaks, and which way that orders the group
+    // 4. where the period breaks, and which way that orders the group.  A step p <= h is a period of
+    // the stretch by itself and its break lies within p symbols (one lane looks for it); a longer
+    // step counts only if the text really has that period over the whole stretch, which
+    // next_break answers -- for one such period per call, that of the first group that has one.
+    const uint32_t short_max = min(h, kMaxPeriod);
+    if (tid == 0) sh.vote = 0ull;
+    __syncthreads();
+    for (uint32_t g = tid; g < G; g += NT) {
+        const uint32_t state = tbl[4u * g + 3u];
+        if ((state & kPeriodGood) && (state & kPeriodMask) > short_max)
+            atomicMax(&sh.vote, ((unsigned long long)tbl[4u * g + 2u] << 32) | (state & kPeriodMask));
+    }
+    __syncthreads();
+    const uint32_t P = (uint32_t)sh.vote;  // the step of the most populous such group
+    uint32_t* next_break = reinterpret_cast<uint32_t*>(spare);  // n + 1 words, dead before the compaction writes there
+    const bool have_breaks = P != 0u;
+    __syncthreads();
+    if (have_breaks) build_next_break<NT>(next_break, P, io, sh);
     auto symbol = [&](uint32_t x) { return x < len ? (int)io.s[x] : (x == len ? (int)io.delim : -1); };
     for (uint32_t g = tid; g < G; g += NT) {
         const uint32_t state = tbl[4u * g + 3u];
         if (!(state & kPeriodGood)) continue;
-        const uint32_t per = state & 0xFFFFu, from = tbl[4u * g + 1u] + h;
-        uint32_t found = 0, asc = 0;
-        for (uint32_t t = 0; t <= per; ++t) {  // the break lies within one period of `from`, or the group would have another member
-            const uint32_t x = from + t;
-            const int a = symbol(x - per), b = symbol(x);
-            if (a != b) {
-                found = 1;
-                asc = a < b ? 1u : 0u;
-                break;
+        const uint32_t per = state & kPeriodMask, mn = tbl[4u * g + 0u], from = tbl[4u * g + 1u] + h;
+        uint32_t E = 0xFFFFFFFFu;
+        if (per <= short_max) {
+            for (uint32_t t = 0; t <= per; ++t) {  // the break lies within one period of `from`, or the group would have another member
+                const uint32_t x = from + t;
+                if (x >= n || symbol(x - per) != symbol(x)) {
+                    E = x;
+                    break;
+                }
             }
-            if (x >= n) break;
+        } else if (have_breaks && per == P && next_break[mn + P] >= from) {
+            E = next_break[from];
         }
-        if (found) {
+        if (E != 0xFFFFFFFFu) {
+            const bool asc = E < n && symbol(E - per) < symbol(E);
             tbl[4u * g + 3u] = state | (asc ? kPeriodAsc : 0u);
             atomicAdd(&sh.chunk_bad, tbl[4u * g + 2u]);
         } else {
@@ -1524,7 +1606,7 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
         for (uint32_t g = 0; g < G; ++g) {
             const uint32_t state = tbl[4u * g + 3u];
             if (!(state & kPeriodGood)) continue;  // workgroup-uniform
-            const uint32_t mn = tbl[4u * g + 0u], cnt = tbl[4u * g + 2u], per = state & 0xFFFFu;
+            const uint32_t mn = tbl[4u * g + 0u], cnt = tbl[4u * g + 2u], per = state & kPeriodMask;
             const uint32_t first = rank[mn];
             __syncthreads();  // every thread has the group's first row before any member's rank changes
             for (uint32_t a = tid; a < cnt; a += NT) {
@@ -1566,7 +1648,7 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
         const uint64_t K = __ballot(valid && !good);
         if (good) {
             if (!by_group) {
-                const uint32_t a = (idx - tbl[4u * g + 0u]) / (state & 0xFFFFu), cnt = tbl[4u * g + 2u];
+                const uint32_t a = (idx - tbl[4u * g + 0u]) / (state & kPeriodMask), cnt = tbl[4u * g + 2u];
                 const uint32_t r = rank[idx] + ((state & kPeriodAsc) ? a : cnt - 1u - a);
                 if (later) rank[idx] = r;
                 if (r < n) io.out[r] = idx ? io.s[idx - 1u] : (uint8_t)io.delim;
@@ -1574,6 +1656,225 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
         } else if (valid) {
             spare[pos + (uint32_t)__popcll(K & lt)] = e;
         }
+        pos += (uint32_t)__popcll(K);
+    }
+    __syncthreads();
+    return m - resolved;
+}
+
+// The same for a list of MANY SHORT groups (text repeated with a long period: every group is a
+// handful of copies of one suffix, one per repetition), without a table: a wave looks at 64
+// consecutive list elements at a time, vectors overlapping by kShortGroup, so that every group of
+// at most kShortGroup members lies inside the vector that holds its first element among the
+// first 64 - kShortGroup lanes.  The first lane of a group gathers minimum, maximum and count by
+// shuffles, every member checks itself against the progression, and a period longer than h is
+// accepted too if the text really has it over the whole stretch -- which, like the place where
+// it breaks, is read from next_break (built once per call for ONE period: the step that most
+// suffixes' groups have, found by a first sweep that only votes).  Resolved elements are marked
+// in the list (lowest bit of the still empty rank field) and dropped by the compaction.  Returns
+// the number of suffixes left (== m: nothing changed, the list is intact).
+constexpr uint32_t kShortGroup = 16;
+constexpr uint32_t kShortStride = kWave - kShortGroup;
+
+struct ShortGroups {
+    uint64_t e;          // my element
+    uint32_t idx;        // its position in the text
+    bool member;         // I belong to a group this vector is responsible for
+    uint32_t head;       // lane of my group's first element
+    uint32_t cnt, mn, per;  // the group's size, lowest position and step (per == 0: not a progression), in every member
+    uint32_t mx;
+};
+
+// Loads the vector at `base` and works out its groups.
+// The element of my lane in the vector at `base` and the element just before the vector.
+struct ShortLoad {
+    uint64_t e, before;
+};
+__device__ __forceinline__ ShortLoad short_load(const uint64_t* list, uint32_t base, uint32_t m) {
+    ShortLoad l;
+    l.e = list[min(base + (uint32_t)lane_id(), m - 1u)];
+    l.before = list[min(base ? base - 1u : 0u, m - 1u)];  // same address in every lane
+    return l;
+}
+
+__device__ __forceinline__ ShortGroups short_groups(const ShortLoad& ld, uint32_t base, uint32_t m, uint32_t h,
+                                                    uint32_t len, uint64_t imask, int gshift) {
+    const int lane = lane_id();
+    ShortGroups r;
+    const uint32_t k = base + (uint32_t)lane;
+    const bool valid = k < m;
+    r.e = ld.e;
+    const uint64_t before = ld.before;
+    r.idx = (uint32_t)(r.e & imask);
+    const uint64_t g = r.e >> gshift;
+    uint64_t gp = __shfl_up(g, 1);
+    if (lane == 0) gp = base ? before >> gshift : ~g;
+    const uint64_t H = __ballot(valid && g != gp);  // first elements of groups
+    const uint64_t upto = H & lanemask_le();
+    r.head = upto ? 63u - (uint32_t)__clzll(upto) : 64u;  // 64: my group began before this vector
+    const bool last_vec = base + kWave >= m;
+    const uint32_t end = last_vec ? m - base : 64u;  // the list ends here / unknown beyond the vector
+    uint64_t later = r.head < 63u ? H & ~((2ull << r.head) - 1ull) : 0ull;
+    const uint32_t next = later ? (uint32_t)__ffsll((unsigned long long)later) - 1u : (last_vec ? end : 65u);
+    r.member = valid && r.head < kShortStride && next <= 64u;  // (lanes < kShortStride of all vectors tile the list: one vector per group)
+    r.cnt = r.member ? next - r.head : 0u;
+    if (r.cnt < 2u || r.cnt > kShortGroup) r.member = false;
+    // minimum and maximum position of the group: gathered by its first lane, handed to the members
+    uint32_t mn = r.idx, mx = r.idx;
+#pragma unroll
+    for (int t = 1; t < (int)kShortGroup; ++t) {
+        const uint32_t v = __shfl_down(r.idx, t);
+        if ((uint32_t)t < r.cnt && (uint32_t)lane == r.head) {
+            mn = min(mn, v);
+            mx = max(mx, v);
+        }
+    }
+    const int src = (int)(r.head & 63u);
+    r.mn = __shfl(mn, src);
+    r.mx = __shfl(mx, src);
+    r.per = 0;
+    if (r.member && (uint64_t)r.mx + h <= (uint64_t)len) {
+        const uint32_t span = r.mx - r.mn, per = span / (r.cnt - 1u);
+        if (per != 0u && per * (r.cnt - 1u) == span) r.per = per;
+    }
+    // every member on the progression?
+    const bool off = r.member && (r.per == 0u || ((r.idx - r.mn) / r.per) * r.per != r.idx - r.mn);
+    const uint64_t OFF = __ballot(off);
+    if (r.member && ((OFF >> r.head) & ((r.cnt < 64u ? (1ull << r.cnt) : 0ull) - 1ull))) r.per = 0;
+    return r;
+}
+
+template <int NT>
+__device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restrict__ list, uint64_t* spare,
+                                                               uint32_t m, uint32_t h, uint32_t* __restrict__ rank,
+                                                               const BlockIO& io, int ibits, int gshift,
+                                                               uint32_t& period_hint, FwdShared<NT>& sh) {
+    constexpr int W = NT / kWave;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint64_t imask = (1ull << ibits) - 1ull, lt = lanemask_lt();
+    const uint32_t n = io.n, len = io.n - 1u;
+    uint32_t* next_break = reinterpret_cast<uint32_t*>(spare);  // n + 1 words, dead before the compaction writes there
+    auto symbol = [&](uint32_t x) { return x < len ? (int)io.s[x] : (x == len ? (int)io.delim : -1); };
+    const uint32_t nvec = (m + kShortStride - 1u) / kShortStride;
+    const uint32_t short_max = min(h, kMaxPeriod);
+    // 1. the long period to prepare for: the one that worked last time, else the step that most
+    // suffixes' groups have (a sweep that only votes, in a small LDS hash table: step, members; a
+    // step that finds no slot within four probes does not run).  Few votes and no short steps: the
+    // list is not (yet) made of such groups, and the call ends there.
+    uint32_t P = period_hint;
+    if (P == 0u) {
+        constexpr uint32_t kVoteSlots = 256;
+        uint32_t* vkey = sh.v.cw;
+        uint32_t* vcnt = sh.v.cw + kVoteSlots;
+        for (uint32_t i = tid; i < 2u * kVoteSlots; i += NT) sh.v.cw[i] = 0;
+        if (tid == 0) {
+            sh.vote = 0ull;
+            sh.chunk_bad = 0;
+        }
+        __syncthreads();
+        uint32_t shorts = 0;
+        ShortLoad ld = short_load(list, (uint32_t)w * kShortStride, m);
+#pragma unroll 1
+        for (uint32_t v = (uint32_t)w; v < nvec; v += W) {
+            const ShortLoad nxt = short_load(list, min(v + W, nvec - 1u) * kShortStride, m);  // in flight while this one is worked on
+            const ShortGroups sg = short_groups(ld, v * kShortStride, m, h, len, imask, gshift);
+            ld = nxt;
+            if (sg.member && (uint32_t)lane == sg.head && sg.per > short_max) {
+                uint32_t slot = (sg.per * 2654435761u) >> 24;
+                for (int probe = 0; probe < 4; ++probe, slot = (slot + 1u) & (kVoteSlots - 1u)) {
+                    const uint32_t old = atomicCAS(&vkey[slot], 0u, sg.per);
+                    if (old == 0u || old == sg.per) {
+                        atomicAdd(&vcnt[slot], sg.cnt);
+                        break;
+                    }
+                }
+            }
+            shorts += (uint32_t)__popcll(__ballot(sg.member && sg.per != 0u && sg.per <= short_max));
+        }
+        if (lane == 0 && shorts) atomicAdd(&sh.chunk_bad, shorts);
+        __syncthreads();
+        for (uint32_t i = tid; i < kVoteSlots; i += NT)
+            if (vcnt[i]) atomicMax(&sh.vote, ((unsigned long long)vcnt[i] << 32) | vkey[i]);
+        __syncthreads();
+        const uint32_t votes = (uint32_t)(sh.vote >> 32), nshort = sh.chunk_bad;
+        P = (uint32_t)sh.vote;
+        __syncthreads();
+        if (votes < m / 8u) P = 0u;
+        if (P == 0u && nshort < m / 8u) return m;
+    }
+    // 2. next_break for P
+    if (P) build_next_break<NT>(next_break, P, io, sh);
+    if (tid == 0) sh.chunk_bad = 0;
+    __syncthreads();
+    // 3. settle the groups that are progressions inside a periodic stretch
+    uint32_t settled = 0;
+    ShortLoad ld = short_load(list, (uint32_t)w * kShortStride, m);
+#pragma unroll 1
+    for (uint32_t v = (uint32_t)w; v < nvec; v += W) {
+        const uint32_t base = v * kShortStride;
+        const ShortLoad nxt = short_load(list, min(v + W, nvec - 1u) * kShortStride, m);
+        const ShortGroups sg = short_groups(ld, base, m, h, len, imask, gshift);
+        ld = nxt;
+        // the first lane of a group finds where the period breaks
+        uint32_t E = 0xFFFFFFFFu;
+        if (sg.member && (uint32_t)lane == sg.head && sg.per != 0u) {
+            if (sg.per <= short_max) {
+                const uint32_t from = sg.mx + h;
+                for (uint32_t t = 0; t <= sg.per; ++t) {
+                    const uint32_t x = from + t;
+                    if (x >= n || symbol(x - sg.per) != symbol(x)) {
+                        E = x;
+                        break;
+                    }
+                }
+            } else if (sg.per == P && next_break[sg.mn + P] >= sg.mx + h) {
+                E = next_break[sg.mx + h];
+            }
+        }
+        uint32_t dir = 0;  // 0 unresolved, 1 descending, 2 ascending
+        if (E != 0xFFFFFFFFu) dir = (E < n && symbol(E - sg.per) < symbol(E)) ? 2u : 1u;
+        dir = __shfl(dir, (int)(sg.head & 63u));
+        const bool done = sg.member && dir != 0u;
+        if (done) {
+            const uint32_t a = (sg.idx - sg.mn) / sg.per;
+            const uint32_t r = rank[sg.idx] + (dir == 2u ? a : sg.cnt - 1u - a);
+            rank[sg.idx] = r;
+            if (r < n) io.out[r] = sg.idx ? io.s[sg.idx - 1u] : (uint8_t)io.delim;
+            list[base + (uint32_t)lane] = sg.e | (1ull << ibits);
+        }
+        settled += (uint32_t)__popcll(__ballot(done));
+    }
+    if (lane == 0 && settled) atomicAdd(&sh.chunk_bad, settled);
+    __syncthreads();
+    const uint32_t resolved = sh.chunk_bad;
+    __syncthreads();
+    period_hint = resolved ? P : 0u;  // a period that settled nothing is not tried again unasked
+    if (resolved == 0) return m;
+    // 4. the others move on in order
+    Chunking ck;
+    ck.init(m, W);
+    const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, m);
+    {
+        uint32_t kept = 0;
+#pragma unroll 1
+        for (uint32_t base = lo; base < hi; base += kWave) {
+            const uint32_t k = base + lane;
+            kept += (uint32_t)__popcll(__ballot(k < hi && !((list[k] >> ibits) & 1ull)));
+        }
+        if (lane == 0) sh.cntA[w] = kept;
+    }
+    __syncthreads();
+    uint32_t pos = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+        if (i < w) pos += sh.cntA[i];
+#pragma unroll 1
+    for (uint32_t base = lo; base < hi; base += kWave) {
+        const uint32_t k = base + lane;
+        const uint64_t e = k < hi ? list[k] : 0ull;
+        const bool keep = k < hi && !((e >> ibits) & 1ull);
+        const uint64_t K = __ballot(keep);
+        if (keep) spare[pos + (uint32_t)__popcll(K & lt)] = e;
         pos += (uint32_t)__popcll(K);
     }
     __syncthreads();
@@ -1736,11 +2037,20 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, sh, m, G);
             else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);
-        } else {
-            // too long for LDS: through HBM -- unless one key makes up nearly all of it (periodic
-            // text, long runs), which takes one read to find out and a few moves to put right
-            const bool constant = settle_dominant_key<NT>(sorted0 + s0, cnt, kshift0, sh);
-            if (!constant) sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
+        }
+    }
+    if (!fused) {
+        // The buckets too long for LDS (kept out of the loop above, which is the hot one): through
+        // HBM -- unless one key makes up nearly all of the bucket (periodic text, long runs),
+        // which takes one read to find out and a few moves to put right
+#pragma unroll 1
+        for (uint32_t k = 0; k < dir.nb; ++k) {
+            const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
+            if (cnt <= (uint32_t)FwdShared<NT>::kSortCap) continue;  // workgroup-uniform
+            const uint32_t f0 = dir.flo[k], f1 = dir.flo[k + 1];
+            if (!settle_dominant_key<NT>(sorted0 + s0, cnt, kshift0, sh))
+                sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, (uint64_t)f0 << r0.fshift,
+                                      r0.fshift + bit_length(f1 - f0 - 1u), sh, &queue[1]);
             pc.lap(11);
         }
     }
@@ -1789,6 +2099,8 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     uint64_t* cur = full ? sorted0 : spare + a.ncap / 2;  // scratch side of the ping-pong
     uint64_t* alt = spare;                                 // holds the survivor list
     uint32_t h = (uint32_t)m0;
+    uint32_t m_before = n;  // the list's length one round earlier
+    uint32_t period_hint = 0;  // the long period that last settled groups of this block (0: none yet)
     for (int round = 1; m > 0; ++round) {
         if (round > 64) {  // cannot happen: h >= n is reached after at most 21 doublings
             if (tid == 0) atomicOr(&queue[1], kErrNotConverged);
@@ -1800,8 +2112,13 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         plan.init(rbits + gbits);
         // small groups: the round runs chunk by chunk inside LDS (the bucket directory's slots hold the cuts)
         uint32_t nchunks = cut_chunks<NT>(alt, m, gshift, (uint32_t)FwdShared<NT>::kSortCap, dir.start, sh);
-        if (full && nchunks == 0) {  // long groups: the ones that are periodic runs are settled at once
-            const uint32_t left = resolve_periodic_groups<NT>(alt, cur, a.ncap, m, G, h, rank, io, ibits, gshift, sh);
+        // Long groups, or a list that has stopped shrinking: the groups that are periodic runs are settled at once
+        const bool stalled = round >= 2 && m > n / 8u && (uint64_t)m * 4u > (uint64_t)m_before * 3u;
+        m_before = m;
+        if (full && (nchunks == 0 || stalled)) {
+            const uint32_t left = G <= kTableGroups
+                                      ? resolve_periodic_groups<NT>(alt, cur, a.ncap, m, G, h, rank, io, ibits, gshift, sh)
+                                      : resolve_short_periodic_groups<NT>(alt, cur, m, h, rank, io, ibits, gshift, period_hint, sh);
             pc.lap(15);
             if (left != m) {
                 uint64_t* t = alt;

@@ -229,6 +229,11 @@ def test_periodic_runs(orc):
                          np.frombuffer(b"q", np.uint8), np.full(50000, 200, np.uint8)]), 1 << 20, None),
         (np.tile(np.frombuffer(b"ba", np.uint8), 70000), 140000, None),
         (np.tile(np.frombuffer(b"abc", np.uint8), 300 * 16384 // 3 + 10), 16384, None),  # more blocks than CUs: 256-thread kernel
+        (np.tile(rng.integers(0, 200, size=1000, dtype=np.uint8), 300), 300000, None),   # period 1000: longer than the lane search
+        (np.tile(np.frombuffer(open(os.path.join(CORPUS, "alice29.txt"), "rb").read(), np.uint8), 8)[:(1 << 20) + 50000],
+         1 << 20, None),                                                          # text tiled with a long period: many short groups
+        (np.concatenate([np.tile(rng.integers(0, 200, size=3000, dtype=np.uint8), 40),
+                         np.tile(rng.integers(0, 200, size=5000, dtype=np.uint8), 30)]), 270000, None),  # two long periods
         (np.full(50000, ord("a"), np.uint8), 50000, ord("a")),                   # the delimiter continues the run
         (np.tile(np.frombuffer(b"abc", np.uint8), 30000), 90000, ord("a")),
     ]
