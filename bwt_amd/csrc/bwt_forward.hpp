@@ -49,7 +49,9 @@ struct FwdArgs {
     uint32_t delim;
     uint8_t* ws;          // workgroup w owns ws + w*ws_stride
     uint64_t ws_stride;
-    uint32_t* queue;      // [0] next block index to hand out, [1] error flags, [16..] phase clocks
+    uint32_t* queue;      // [0] next block index to hand out, [1] error flags, [2] blocks put off, [3] next put-off
+                          // block to hand out, [16..] phase clocks
+    uint32_t* deferred;   // nblocks words: the blocks the first launch put off for the second
 };
 
 constexpr uint32_t kErrNotConverged = 1u;
@@ -80,7 +82,9 @@ constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition a
 // sweep (when not fused), 4 later key builds, 5 later sorts, 6 later reranks, 7 full-rank
 // rebuilds, 8 blocks, 9 later rounds, 10 round-0 rerank of buckets in LDS (or their plain
 // write-back), 11 round-0 bucket sorts through HBM, 12 round-0 bucket sorts in LDS, 13 / 14 later
-// rounds' chunk sorts / chunk reranks in LDS, 15 periodic-run resolution.
+// rounds' chunk sorts / chunk reranks in LDS, 15 periodic-run resolution (of which, for lists of
+// many short groups: 16 the vote, 17 the next-break table, 18 the settling sweep; the rest of 15 is
+// the compaction and the table variant).
 struct PhaseClock {
     unsigned long long t;
     unsigned long long* acc;
@@ -1748,7 +1752,7 @@ template <int NT>
 __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restrict__ list, uint64_t* spare,
                                                                uint32_t m, uint32_t h, uint32_t* __restrict__ rank,
                                                                const BlockIO& io, int ibits, int gshift,
-                                                               uint32_t& period_hint, FwdShared<NT>& sh) {
+                                                               uint32_t& period_hint, PhaseClock& pc, FwdShared<NT>& sh) {
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint64_t imask = (1ull << ibits) - 1ull, lt = lanemask_lt();
@@ -1800,55 +1804,92 @@ __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restr
         P = (uint32_t)sh.vote;
         __syncthreads();
         if (votes < m / 8u) P = 0u;
+        pc.lap(16);
         if (P == 0u && nshort < m / 8u) return m;
     }
     // 2. next_break for P
     if (P) build_next_break<NT>(next_break, P, io, sh);
     if (tid == 0) sh.chunk_bad = 0;
     __syncthreads();
-    // 3. settle the groups that are progressions inside a periodic stretch
+    pc.lap(17);
+    // 3. settle the groups that are progressions inside a periodic stretch.  Every step is a chain
+    // of dependent loads (list -> next_break twice -> two text bytes -> rank), so four vectors go
+    // through it side by side.
     uint32_t settled = 0;
-    ShortLoad ld = short_load(list, (uint32_t)w * kShortStride, m);
+    constexpr int U = 4;
 #pragma unroll 1
-    for (uint32_t v = (uint32_t)w; v < nvec; v += W) {
-        const uint32_t base = v * kShortStride;
-        const ShortLoad nxt = short_load(list, min(v + W, nvec - 1u) * kShortStride, m);
-        const ShortGroups sg = short_groups(ld, base, m, h, len, imask, gshift);
-        ld = nxt;
-        // the first lane of a group finds where the period breaks
-        uint32_t E = 0xFFFFFFFFu;
-        if (sg.member && (uint32_t)lane == sg.head && sg.per != 0u) {
-            if (sg.per <= short_max) {
-                const uint32_t from = sg.mx + h;
-                for (uint32_t t = 0; t <= sg.per; ++t) {
+    for (uint32_t v0 = (uint32_t)w * U; v0 < nvec; v0 += W * U) {
+        ShortLoad ld[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) ld[u] = short_load(list, min(v0 + (uint32_t)u, nvec - 1u) * kShortStride, m);
+        ShortGroups sg[U];
+        bool lead[U];  // my lane speaks for a candidate group
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sg[u] = short_groups(ld[u], (v0 + (uint32_t)u) * kShortStride, m, h, len, imask, gshift);
+            if (v0 + (uint32_t)u >= nvec) sg[u].member = false;
+            lead[u] = sg[u].member && (uint32_t)lane == sg[u].head && sg[u].per != 0u;
+        }
+        uint32_t E[U], nb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            E[u] = 0xFFFFFFFFu;
+            nb[u] = 0;
+            if (lead[u] && sg[u].per > short_max && sg[u].per == P) nb[u] = next_break[sg[u].mn + P];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!lead[u]) continue;
+            if (sg[u].per <= short_max) {
+                const uint32_t from = sg[u].mx + h;
+                for (uint32_t t = 0; t <= sg[u].per; ++t) {
                     const uint32_t x = from + t;
-                    if (x >= n || symbol(x - sg.per) != symbol(x)) {
-                        E = x;
+                    if (x >= n || symbol(x - sg[u].per) != symbol(x)) {
+                        E[u] = x;
                         break;
                     }
                 }
-            } else if (sg.per == P && next_break[sg.mn + P] >= sg.mx + h) {
-                E = next_break[sg.mx + h];
+            } else if (sg[u].per == P && nb[u] >= sg[u].mx + h) {
+                E[u] = next_break[sg[u].mx + h];
             }
         }
-        uint32_t dir = 0;  // 0 unresolved, 1 descending, 2 ascending
-        if (E != 0xFFFFFFFFu) dir = (E < n && symbol(E - sg.per) < symbol(E)) ? 2u : 1u;
-        dir = __shfl(dir, (int)(sg.head & 63u));
-        const bool done = sg.member && dir != 0u;
-        if (done) {
-            const uint32_t a = (sg.idx - sg.mn) / sg.per;
-            const uint32_t r = rank[sg.idx] + (dir == 2u ? a : sg.cnt - 1u - a);
-            rank[sg.idx] = r;
-            if (r < n) io.out[r] = sg.idx ? io.s[sg.idx - 1u] : (uint8_t)io.delim;
-            list[base + (uint32_t)lane] = sg.e | (1ull << ibits);
+        int sa[U], sb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sa[u] = sb[u] = 0;
+            if (E[u] != 0xFFFFFFFFu) {
+                sa[u] = symbol(E[u] - sg[u].per);
+                sb[u] = E[u] < n ? symbol(E[u]) : -1;
+            }
         }
-        settled += (uint32_t)__popcll(__ballot(done));
+        bool done[U];
+        uint32_t dir[U], rk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t d = 0;  // 0 unresolved, 1 descending, 2 ascending
+            if (E[u] != 0xFFFFFFFFu) d = (E[u] < n && sa[u] < sb[u]) ? 2u : 1u;
+            dir[u] = __shfl(d, (int)(sg[u].head & 63u));
+            done[u] = sg[u].member && dir[u] != 0u;
+            rk[u] = done[u] ? rank[sg[u].idx] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (done[u]) {
+                const uint32_t a = (sg[u].idx - sg[u].mn) / sg[u].per;
+                const uint32_t r = rk[u] + (dir[u] == 2u ? a : sg[u].cnt - 1u - a);
+                rank[sg[u].idx] = r;
+                if (r < n) io.out[r] = sg[u].idx ? io.s[sg[u].idx - 1u] : (uint8_t)io.delim;
+                list[(v0 + (uint32_t)u) * kShortStride + (uint32_t)lane] = sg[u].e | (1ull << ibits);
+            }
+            settled += (uint32_t)__popcll(__ballot(done[u]));
+        }
     }
     if (lane == 0 && settled) atomicAdd(&sh.chunk_bad, settled);
     __syncthreads();
     const uint32_t resolved = sh.chunk_bad;
     __syncthreads();
     period_hint = resolved ? P : 0u;  // a period that settled nothing is not tried again unasked
+    pc.lap(18);
     if (resolved == 0) return m;
     // 4. the others move on in order
     Chunking ck;
@@ -1881,10 +1922,17 @@ __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restr
     return m - resolved;
 }
 
-template <int NT>
+// HEAVY = false leaves out the machinery for blocks whose suffixes stay tied in long groups
+// (periodic runs, keys that dominate a bucket: cold code that costs the common case registers):
+// such a block is put off -- its index appended to a.deferred, nothing of it kept -- and done
+// from the start by a second launch of the HEAVY = true instantiation.
+template <int NT, bool HEAVY>
 __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
                                               uint8_t* __restrict__ out, uint64_t* bufA, uint64_t* bufB,
-                                              uint32_t* rank, FwdShared<NT>& sh, const FwdArgs& a) {
+                                              uint32_t* rank, FwdShared<NT>& sh, const FwdArgs& a, uint32_t b) {
+    auto put_off = [&]() {
+        if (threadIdx.x == 0) a.deferred[atomicAdd(&a.queue[2], 1u)] = b;
+    };
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t* queue = a.queue;
@@ -1981,6 +2029,12 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     const uint32_t target = max(kBucketTarget, (n + (uint32_t)kMaxBuckets - 1u) / (uint32_t)kMaxBuckets);
     dir.flo = dir.start + (kMaxBuckets + 1);
     assign_buckets<NT>(sh, n, target, fbits, dir);
+    bool fused = true;  // every bucket fits LDS
+    for (uint32_t k = 0; k < dir.nb; ++k) fused = fused && dir.start[k + 1] - dir.start[k] <= (uint32_t)FwdShared<NT>::kSortCap;
+    if (!HEAVY && !fused) {  // workgroup-uniform
+        put_off();
+        return;
+    }
     const bool two_pass = dir.nb > (uint32_t)kBins;
     const int b1 = two_pass ? 4 : kMaxDigitBits;
     dig.mask = (1u << b1) - 1u;
@@ -2020,8 +2074,6 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     const int gshift = ibits + rbits;
     // When every bucket fits LDS the rerank is done on the sorted bucket while it is still
     // there (survivor ranks only); otherwise, or when many suffixes survive, a separate sweep does it.
-    bool fused = true;
-    for (uint32_t k = 0; k < dir.nb; ++k) fused = fused && dir.start[k + 1] - dir.start[k] <= (uint32_t)FwdShared<NT>::kSortCap;
     uint32_t m = 0, G = 0;
     for (uint32_t k = 0; k < dir.nb; ++k) {
         const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
@@ -2039,7 +2091,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             pc.lap(10);
         }
     }
-    if (!fused) {
+    if (HEAVY && !fused) {
         // The buckets too long for LDS (kept out of the loop above, which is the hot one): through
         // HBM -- unless one key makes up nearly all of the bucket (periodic text, long runs),
         // which takes one read to find out and a few moves to put right
@@ -2115,10 +2167,14 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         // Long groups, or a list that has stopped shrinking: the groups that are periodic runs are settled at once
         const bool stalled = round >= 2 && m > n / 8u && (uint64_t)m * 4u > (uint64_t)m_before * 3u;
         m_before = m;
-        if (full && (nchunks == 0 || stalled)) {
+        if (!HEAVY && full && (nchunks == 0 || stalled)) {  // workgroup-uniform
+            put_off();
+            return;
+        }
+        if (HEAVY && full && (nchunks == 0 || stalled)) {
             const uint32_t left = G <= kTableGroups
                                       ? resolve_periodic_groups<NT>(alt, cur, a.ncap, m, G, h, rank, io, ibits, gshift, sh)
-                                      : resolve_short_periodic_groups<NT>(alt, cur, m, h, rank, io, ibits, gshift, period_hint, sh);
+                                      : resolve_short_periodic_groups<NT>(alt, cur, m, h, rank, io, ibits, gshift, period_hint, pc, sh);
             pc.lap(15);
             if (left != m) {
                 uint64_t* t = alt;
@@ -2231,23 +2287,25 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     pc.count(8, 1);
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT, NT <= 256 ? 3 : 4) void bwt_forward_kernel(FwdArgs a) {
+template <int NT, bool HEAVY>
+__global__ __launch_bounds__(NT, NT <= 256 ? 3 : 4) void bwt_forward_kernel(FwdArgs a, int second) {
     __shared__ FwdShared<NT> sh;
     uint64_t* bufA = reinterpret_cast<uint64_t*>(a.ws + (uint64_t)blockIdx.x * a.ws_stride);
     uint64_t* bufB = bufA + a.ncap;
     uint32_t* rank = reinterpret_cast<uint32_t*>(bufB + a.ncap);
     for (;;) {
-        if (threadIdx.x == 0) sh.blk = atomicAdd(&a.queue[0], 1u);
+        // first launch: all blocks in order; second launch: the blocks the first one put off
+        if (threadIdx.x == 0) sh.blk = atomicAdd(&a.queue[second ? 3 : 0], 1u);
         __syncthreads();
-        const uint32_t b = sh.blk;
+        uint32_t b = sh.blk;
         __syncthreads();
-        if (b >= a.nblocks) break;
+        if (b >= (second ? a.queue[2] : a.nblocks)) break;
+        if (second) b = a.deferred[b];
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint64_t rem = a.total_len - off;
         const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;
-        forward_block<NT>(a.in + off, len, a.delim, a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u), bufA, bufB,
-                          rank, sh, a);
+        forward_block<NT, HEAVY>(a.in + off, len, a.delim, a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u), bufA,
+                                 bufB, rank, sh, a, b);
         __syncthreads();
     }
 }

@@ -183,7 +183,7 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     // With fewer blocks than compute units most of the chip idles and a block's latency is the
     // whole cost: give every block a 1024-thread workgroup instead.
     g.wide = g.nblocks <= (size_t)d.cus && longest >= kWideMinBlock;
-    g.bytes = kHeaderBytes + g.stride * g.grid;
+    g.bytes = kHeaderBytes + g.stride * g.grid + round_up(g.nblocks * 4, 256);  // + the list of blocks put off
     // The device-wide path serves the batch itself or, when a caller sizes its workspace for a
     // full slab and then submits a shorter one, any prefix of it.
     const int forced = forced_forward_path();
@@ -386,7 +386,7 @@ int ensure_device(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d->cus = prop.multiProcessorCount;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bwt_forward_kernel<kFwdThreads>, kFwdThreads, 0) ==
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bwt_forward_kernel<kFwdThreads, false>, kFwdThreads, 0) ==
             hipSuccess && occ > 0)
         d->fwd_wgs_per_cu = occ;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bwt_inverse_build_kernel<kInvThreads>, kInvThreads, 0) ==
@@ -665,6 +665,7 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     a.ws = (uint8_t*)d_workspace + kHeaderBytes;
     a.ws_stride = g.stride;
     a.queue = (uint32_t*)d_workspace;
+    a.deferred = (uint32_t*)((uint8_t*)d_workspace + kHeaderBytes + g.stride * g.grid);
     if (g.grid_path) return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
     if (block_size > kBlockKernelMaxBlock)
         return fail(BWTGPU_ERR_INVALID, "a batch of blocks above %zu bytes may hold at most 2^31 bytes (%zu given): split it",
@@ -673,8 +674,14 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
         const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
         hipLaunchKernelGGL(bwt_forward_small_kernel, dim3(grid), dim3(kSmallWaves * kWave), 0, s, a);
-    } else if (g.wide) hipLaunchKernelGGL(bwt_forward_kernel<kFwdWideThreads>, dim3(g.grid), dim3(kFwdWideThreads), 0, s, a);
-    else hipLaunchKernelGGL(bwt_forward_kernel<kFwdThreads>, dim3(g.grid), dim3(kFwdThreads), 0, s, a);
+    } else if (g.wide) {
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, true>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 0);
+    } else {
+        // the common case first; the blocks it puts off (periodic runs, dominant keys) in a second
+        // launch of the full kernel, which finds an empty list otherwise
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, true>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 1);
+    }
     HIP_TRY(hipGetLastError());
     return BWTGPU_OK;
 }
