@@ -1458,6 +1458,7 @@ __device__ __noinline__ void build_next_break(uint32_t* __restrict__ next_break,
 // number of suffixes left (== m: nothing was resolved and `list` is still the list; else the
 // list is now in `spare`).
 constexpr uint32_t kMaxPeriod = 256;  // the break of the period is searched by one lane per group
+constexpr uint32_t kFewGroups = 256;     // a round through HBM with at most this many groups: periodic text, most likely
 constexpr uint32_t kTableGroups = 2048;  // more groups than this: no table, one thread walks each (short) group
 constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u, kPeriodMask = 0x00FFFFFFu;
 
@@ -1529,7 +1530,13 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
             if (per * (cnt - 1u) == span && per >= 1u) state = kPeriodGood | per;
         }
         tbl[4u * g + 3u] = state;
+        if (state) sh.chunk_bad = 1;  // (cleared above; counts the settled suffixes from step 4 on)
     }
+    __syncthreads();
+    const bool any_candidate = sh.chunk_bad != 0u;
+    __syncthreads();
+    if (!any_candidate) return m;  // the usual outcome for text: nothing here is a progression
+    if (tid == 0) sh.chunk_bad = 0;
     __syncthreads();
     // 3. every member on the progression?  (count distinct positions, all congruent, within the span: then it is the progression)
 #pragma unroll 1
@@ -1777,10 +1784,11 @@ __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restr
         }
         __syncthreads();
         uint32_t shorts = 0;
-        ShortLoad ld = short_load(list, (uint32_t)w * kShortStride, m);
+        constexpr uint32_t kSample = 8;  // one vector in kSample votes: the list is either made of such groups or it is not
+        ShortLoad ld = short_load(list, (uint32_t)w * kSample * kShortStride, m);
 #pragma unroll 1
-        for (uint32_t v = (uint32_t)w; v < nvec; v += W) {
-            const ShortLoad nxt = short_load(list, min(v + W, nvec - 1u) * kShortStride, m);  // in flight while this one is worked on
+        for (uint32_t v = (uint32_t)w * kSample; v < nvec; v += W * kSample) {
+            const ShortLoad nxt = short_load(list, min(v + W * kSample, nvec - 1u) * kShortStride, m);  // in flight while this one is worked on
             const ShortGroups sg = short_groups(ld, v * kShortStride, m, h, len, imask, gshift);
             ld = nxt;
             if (sg.member && (uint32_t)lane == sg.head && sg.per > short_max) {
@@ -1803,9 +1811,9 @@ __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restr
         const uint32_t votes = (uint32_t)(sh.vote >> 32), nshort = sh.chunk_bad;
         P = (uint32_t)sh.vote;
         __syncthreads();
-        if (votes < m / 8u) P = 0u;
+        if (votes * kSample < m / 8u) P = 0u;
         pc.lap(16);
-        if (P == 0u && nshort < m / 8u) return m;
+        if (P == 0u && nshort * kSample < m / 8u) return m;
     }
     // 2. next_break for P
     if (P) build_next_break<NT>(next_break, P, io, sh);
@@ -2030,8 +2038,15 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     dir.flo = dir.start + (kMaxBuckets + 1);
     assign_buckets<NT>(sh, n, target, fbits, dir);
     bool fused = true;  // every bucket fits LDS
-    for (uint32_t k = 0; k < dir.nb; ++k) fused = fused && dir.start[k + 1] - dir.start[k] <= (uint32_t)FwdShared<NT>::kSortCap;
-    if (!HEAVY && !fused) {  // workgroup-uniform
+    uint32_t longest_bucket = 0;
+    for (uint32_t k = 0; k < dir.nb; ++k) {
+        const uint32_t cnt = dir.start[k + 1] - dir.start[k];
+        fused = fused && cnt <= (uint32_t)FwdShared<NT>::kSortCap;
+        longest_bucket = max(longest_bucket, cnt);
+    }
+    // a bucket with a sixteenth of the block under one key prefix: a dominant key (text has buckets
+    // too long for LDS as well, but not of that size; those are sorted through HBM right here)
+    if (!HEAVY && !fused && longest_bucket > n / 16u) {  // workgroup-uniform
         put_off();
         return;
     }
@@ -2091,7 +2106,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             pc.lap(10);
         }
     }
-    if (HEAVY && !fused) {
+    if (!fused) {
         // The buckets too long for LDS (kept out of the loop above, which is the hot one): through
         // HBM -- unless one key makes up nearly all of the bucket (periodic text, long runs),
         // which takes one read to find out and a few moves to put right
@@ -2100,7 +2115,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
             if (cnt <= (uint32_t)FwdShared<NT>::kSortCap) continue;  // workgroup-uniform
             const uint32_t f0 = dir.flo[k], f1 = dir.flo[k + 1];
-            if (!settle_dominant_key<NT>(sorted0 + s0, cnt, kshift0, sh))
+            if (!(HEAVY && settle_dominant_key<NT>(sorted0 + s0, cnt, kshift0, sh)))
                 sort_range_global<NT>(sorted0 + s0, spare + s0, cnt, kshift0, (uint64_t)f0 << r0.fshift,
                                       r0.fshift + bit_length(f1 - f0 - 1u), sh, &queue[1]);
             pc.lap(11);
@@ -2167,11 +2182,15 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         // Long groups, or a list that has stopped shrinking: the groups that are periodic runs are settled at once
         const bool stalled = round >= 2 && m > n / 8u && (uint64_t)m * 4u > (uint64_t)m_before * 3u;
         m_before = m;
-        if (!HEAVY && full && (nchunks == 0 || stalled)) {  // workgroup-uniform
+        // (long groups are common in the first rounds of plain text, but then there are thousands of groups)
+        // ... and a text in which (nearly) every suffix still has a twin after round 0 is repeated text
+        const bool all_twins = round == 1 && n - m <= 64u;
+        const bool suspect = full && (stalled || (nchunks == 0 && (G <= kFewGroups || all_twins)));
+        if (!HEAVY && suspect) {  // workgroup-uniform
             put_off();
             return;
         }
-        if (HEAVY && full && (nchunks == 0 || stalled)) {
+        if (HEAVY && suspect) {
             const uint32_t left = G <= kTableGroups
                                       ? resolve_periodic_groups<NT>(alt, cur, a.ncap, m, G, h, rank, io, ibits, gshift, sh)
                                       : resolve_short_periodic_groups<NT>(alt, cur, m, h, rank, io, ibits, gshift, period_hint, pc, sh);

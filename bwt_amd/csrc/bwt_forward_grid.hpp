@@ -51,7 +51,7 @@ struct GridArgs {
     const uint32_t* presence;  // 256-bit mask of the byte values in `in`
     uint32_t* tile_hist;  // kGridBins * kGridMaxTiles words
     uint32_t* tile_rec;   // 4 * kGridMaxTiles words
-    uint32_t* count;      // [0] suffixes still tied after the round
+    uint32_t* count;      // [0] suffixes still tied after the round, [1] suffixes settled as periodic runs since the host last looked
 };
 
 // Row-space position -> block, offset in the block's text (len = the delimiter's position).
@@ -412,6 +412,141 @@ __global__ __launch_bounds__(kGridThreads) void grid_rank_apply_kernel(GridArgs 
         carr = max(carr, tr);
         carn += tn;
     }
+}
+
+// ---- periodic runs: whole groups resolved in one step ------------------------------------------------
+// A group of tied suffixes whose positions form an arithmetic progression i, i+p, i+2p, ... with
+// p <= h lies inside a stretch of the text with period p (each member's h symbols overlap the next
+// member's), and any two neighbours agree exactly up to the one position E where that period
+// breaks; text[E-p] against text[E] (the end of the block lowest, src/bwt.cpp:77-79) therefore
+// orders the whole group: ascending position, or descending.  Plain doubling needs
+// log2(run length / h) more rounds for it (ptt5, a fax bitmap full of zero runs: 14 rounds).
+// Run by the host when a round has left the list nearly as long as it was.  Groups are named by
+// their rank (the row of their first suffix), which indexes two tables in buffers that are idle
+// between rounds: {min, max} and {count, state} of the members' positions.  Five small kernels
+// over the tied list: clear the groups' entries; gather min / max / count; every member checks that
+// it lies on the progression; the first member of a group finds E (at most p <= kGridMaxPeriod
+// steps: were the run longer the group would have another member) and notes the direction; the
+// members take their final ranks and store their output bytes.  They stay in the list for one
+// more round, where their now unique ranks make them drop out as finished.
+constexpr uint32_t kGridMaxPeriod = 256;
+constexpr uint32_t kGridRunBad = 1u, kGridRunDone = 2u, kGridRunAsc = 4u;
+
+// The step of the progression a group with these statistics can be, or 0.
+__device__ __forceinline__ uint32_t grid_run_step(const GridArgs& a, uint2 mm, uint32_t cnt, uint64_t h) {
+    if (cnt < 2u) return 0u;
+    const GridPos p = grid_pos(a, mm.y);           // of the highest member: all h symbols inside the block?
+    if ((uint64_t)p.off + h > (uint64_t)p.len) return 0u;
+    const uint32_t span = mm.y - mm.x, per = span / (cnt - 1u);
+    if (per == 0u || per * (cnt - 1u) != span || (uint64_t)per > h || per > kGridMaxPeriod) return 0u;
+    return per;
+}
+
+__global__ __launch_bounds__(kGridThreads) void grid_runs_clear_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, uint2* __restrict__ tmm,
+                                                                       uint2* __restrict__ tcs) {
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+        const uint32_t r = a.rank[id[j]];
+        tmm[r] = make_uint2(0xFFFFFFFFu, 0u);
+        tcs[r] = make_uint2(0u, 0u);
+    }
+}
+
+__global__ __launch_bounds__(kGridThreads) void grid_runs_stats_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, uint2* __restrict__ tmm,
+                                                                       uint2* __restrict__ tcs) {
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    const int lane = lane_id();
+    for (uint32_t j0 = blockIdx.x * kGridThreads + (threadIdx.x & ~63u); j0 < m; j0 += nthreads) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool valid = j < m;
+        const uint32_t g = id[valid ? j : j0];
+        const uint32_t r = a.rank[g];
+        const uint32_t r0 = __shfl(r, 0);
+        if (__ballot(valid && r != r0) == 0ull) {  // the vector lies inside one group: one update
+            uint32_t mn = valid ? g : 0xFFFFFFFFu, mx = valid ? g : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+                mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+            }
+            const uint32_t members = (uint32_t)__popcll(__ballot(valid));
+            if (lane == 0) {
+                atomicMin(&tmm[r0].x, mn);
+                atomicMax(&tmm[r0].y, mx);
+                atomicAdd(&tcs[r0].x, members);
+            }
+        } else if (valid) {
+            atomicMin(&tmm[r].x, g);
+            atomicMax(&tmm[r].y, g);
+            atomicAdd(&tcs[r].x, 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kGridThreads) void grid_runs_check_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, uint64_t h,
+                                                                       const uint2* __restrict__ tmm,
+                                                                       uint2* __restrict__ tcs) {
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+        const uint32_t g = id[j], r = a.rank[g];
+        const uint2 mm = tmm[r];
+        const uint32_t per = grid_run_step(a, mm, tcs[r].x, h);
+        if (per && (g - mm.x) % per != 0u) atomicOr(&tcs[r].y, kGridRunBad);
+    }
+}
+
+__global__ __launch_bounds__(kGridThreads) void grid_runs_break_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, uint64_t h,
+                                                                       const uint2* __restrict__ tmm,
+                                                                       uint2* __restrict__ tcs) {
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+        const uint32_t g = id[j], r = a.rank[g];
+        if (j && a.rank[id[j - 1u]] == r) continue;  // not the group's first member
+        const uint2 mm = tmm[r];
+        const uint2 cs = tcs[r];
+        const uint32_t per = grid_run_step(a, mm, cs.x, h);
+        if (per == 0u || (cs.y & kGridRunBad)) continue;
+        const GridPos p = grid_pos(a, mm.y);
+        const uint8_t* __restrict__ s = a.in + (uint64_t)p.b * a.block_size;
+        auto symbol = [&](uint32_t off) { return off < p.len ? (int)s[off] : (off == p.len ? (int)a.delim : -1); };
+        const uint32_t from = p.off + (uint32_t)h;  // offsets in the block from here on
+        for (uint32_t t = 0; t <= per; ++t) {
+            const uint32_t x = from + t;
+            const int before = symbol(x - per), here = symbol(x);
+            if (before != here) {
+                tcs[r].y = kGridRunDone | (before < here ? kGridRunAsc : 0u) | (per << 8);
+                break;
+            }
+            if (x > p.len) break;
+        }
+    }
+}
+
+// (count[1] += the suffixes settled: the host reads it with the round's count and tries less often
+// when it stays small)
+__global__ __launch_bounds__(kGridThreads) void grid_runs_apply_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, const uint2* __restrict__ tmm,
+                                                                       const uint2* __restrict__ tcs) {
+    const uint32_t nthreads = gridDim.x * kGridThreads;
+    uint32_t settled = 0;
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+        const uint32_t g = id[j], r = a.rank[g];
+        const uint2 cs = tcs[r];
+        if (!(cs.y & kGridRunDone)) continue;
+        ++settled;
+        const uint32_t per = cs.y >> 8, k = (g - tmm[r].x) / per;
+        const uint32_t nr = r + ((cs.y & kGridRunAsc) ? k : cs.x - 1u - k);
+        a.rank[g] = nr;
+        const GridPos p = grid_pos(a, g);
+        a.out[nr] = p.off ? a.in[(uint64_t)p.b * a.block_size + p.off - 1u] : (uint8_t)a.delim;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) settled += __shfl_xor(settled, o);
+    if (lane_id() == 0 && settled) atomicAdd(&a.count[1], settled);
 }
 
 // ---- the last rounds in one launch ----------------------------------------------------------------

@@ -148,7 +148,7 @@ GridGeom grid_geom(size_t total_len, size_t block_size) {
         return at;
     };
     g.presence_off = take(32);
-    g.count_off = take(4);
+    g.count_off = take(8);
     g.hist_off = take((size_t)kGridBins * kGridMaxTiles * 4);
     g.rec_off = take((size_t)kGridMaxTiles * 16);
     g.rank_off = take(g.rows * 4);
@@ -438,6 +438,7 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
 
     // byte values in the batch -> symbol width and how many symbols the first key holds
     HIP_TRY(hipMemsetAsync(ws + g.presence_off, 0, 32, s));
+    HIP_TRY(hipMemsetAsync(ws + g.count_off, 0, 8, s));
     hipLaunchKernelGGL(presence_kernel, dim3(stream_grid(d, total_len, 256 * 64)), dim3(256), 0, s, d_in, total_len,
                        (uint32_t*)(ws + g.presence_off));
     HIP_TRY(hipGetLastError());
@@ -454,6 +455,7 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     const int b1 = bit_length(a.rows - 1u), b2 = bit_length((uint32_t)longest);
 
     int cur = 0;  // key[cur] / id[cur] hold the list the next step reads
+    uint32_t runs_settled = 0;  // suffixes the periodic-run step has settled so far (device counter, read every round)
     auto sort = [&](uint32_t m, int bits) -> int {
         const uint32_t tile = grid_tile(m), ntiles = (m + tile - 1) / tile;
         for (int shift = 0; shift < bits; shift += kGridDigitBits) {
@@ -476,9 +478,10 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
         hipLaunchKernelGGL(grid_rank_apply_kernel, dim3(ntiles), dim3(kGridThreads), 0, s, a, key[cur], id[cur], m,
                            tile, (uint32_t)b2, round0 ? 1 : 0, a.tile_rec, id[cur ^ 1]);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host, a.count, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(host, a.count, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         *left = host[0];
+        runs_settled = host[1];
         cur ^= 1;  // the tied suffixes are the next list
         return BWTGPU_OK;
     };
@@ -493,8 +496,29 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     const bool trace = std::getenv("BWTGPU_TRACE") != nullptr;  // debugging aid: suffixes left after every round
     if (trace) fprintf(stderr, "bwtgpu grid forward: rows %u, %d symbols of %d bits first, %u tied\n", a.rows, m0, sbits, m);
     uint64_t h = (uint64_t)m0;
+    uint32_t m_before = a.rows;  // the list's length one round earlier
+    bool runs_tried = false;
+    uint32_t runs_m = 0, runs_wait = 0, runs_backoff = 1;
     for (int round = 0; m; ++round) {
         if (round >= 64 || m > a.rows) return fail(BWTGPU_ERR_INTERNAL, "device-wide suffix sort did not converge");
+        // The periodic-run step: when a round has left the list nearly as long as it was (right after
+        // the first sort: only if hardly anything is settled), and less and less often while it finds little.
+        const bool stalled = round == 0 ? (uint64_t)m * 50 > (uint64_t)m_before * 49 : (uint64_t)m * 10 > (uint64_t)m_before * 9;
+        if (runs_wait) --runs_wait;
+        else if (m > kGridFinishCap && stalled) {
+            const dim3 grid(stream_grid(d, m, kGridThreads * 4)), block(kGridThreads);
+            uint2* tmm = (uint2*)key[cur];        // both key buffers are idle between the rank step and the next keys
+            uint2* tcs = (uint2*)key[cur ^ 1];
+            hipLaunchKernelGGL(grid_runs_clear_kernel, grid, block, 0, s, a, id[cur], m, tmm, tcs);
+            hipLaunchKernelGGL(grid_runs_stats_kernel, grid, block, 0, s, a, id[cur], m, tmm, tcs);
+            hipLaunchKernelGGL(grid_runs_check_kernel, grid, block, 0, s, a, id[cur], m, h, tmm, tcs);
+            hipLaunchKernelGGL(grid_runs_break_kernel, grid, block, 0, s, a, id[cur], m, h, tmm, tcs);
+            hipLaunchKernelGGL(grid_runs_apply_kernel, grid, block, 0, s, a, id[cur], m, tmm, tcs);
+            HIP_TRY(hipGetLastError());
+            runs_tried = true;
+            runs_m = m;
+        }
+        m_before = m;
         if (m <= kGridFinishCap) {  // few left: one workgroup runs the remaining rounds by itself
             hipLaunchKernelGGL(grid_finish_kernel, dim3(1), dim3(kGridFinishThreads), 0, s, a, id[cur], m, h, (uint32_t)b1,
                                (uint32_t)b2);
@@ -505,7 +529,13 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
                            id[cur], m, h, (uint32_t)b2, key[cur]);
         HIP_TRY(hipGetLastError());
         if ((rc = sort(m, b1 + b2))) return rc;
+        const uint32_t settled_before = runs_settled;
         if ((rc = rerank(m, false, &m))) return rc;
+        if (runs_tried) {  // did it pay?  if not, wait twice as many rounds before the next try
+            runs_tried = false;
+            if (runs_settled - settled_before < runs_m / 16u) runs_wait = runs_backoff, runs_backoff *= 2;
+            else runs_backoff = 1;
+        }
         if (trace) fprintf(stderr, "bwtgpu grid forward: depth %llu, %u tied\n", (unsigned long long)(2 * h), m);
         h *= 2;
     }
@@ -675,7 +705,8 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
         hipLaunchKernelGGL(bwt_forward_small_kernel, dim3(grid), dim3(kSmallWaves * kWave), 0, s, a);
     } else if (g.wide) {
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, true>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, false>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, true>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 1);
     } else {
         // the common case first; the blocks it puts off (periodic runs, dominant keys) in a second
         // launch of the full kernel, which finds an empty list otherwise
