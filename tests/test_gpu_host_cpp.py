@@ -78,6 +78,12 @@ def test_cli_contract(tmp_path):
     assert open(f2, "rb").read() == open(f, "rb").read()
     assert run([inv, f2, b2, "5000000000"]).returncode == 0
     assert open(b2, "rb").read() == open(src, "rb").read()
+    # BWT_DEVICES asks for more GPUs than there may be: capped to what the library bound, same bytes
+    f3 = str(tmp_path / "g3.bwt")
+    r = subprocess.run([bwt, src, f3, "1048576"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, BWT_DEVICES="4"))
+    assert r.returncode == 0, r.stderr
+    assert open(f3, "rb").read() == open(f, "rb").read()
     # empty file -> 1-byte output (delimiter 0x00); inverting it gives an empty file
     e, ef, eb = str(tmp_path / "e"), str(tmp_path / "e.bwt"), str(tmp_path / "e.out")
     open(e, "wb").close()
