@@ -1464,14 +1464,13 @@ constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u, kPeriodM
 
 template <int NT>
 __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restrict__ list, uint64_t* spare,
-                                                            uint32_t ncap, uint32_t m, uint32_t G, uint32_t h,
+                                                            uint32_t m, uint32_t G, uint32_t h,
                                                             uint32_t* __restrict__ rank, const BlockIO& io, int ibits,
                                                             int gshift, FwdShared<NT>& sh) {
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     static_assert(FwdShared<NT>::kSortCap * 2 >= 4 * (int)kTableGroups, "the group table lives in the LDS sort buffer");
     if (G > kTableGroups) return m;  // workgroup-uniform
-    (void)ncap;
     uint32_t* tbl = reinterpret_cast<uint32_t*>(sh.u.lsort);  // per group: min, max, count, state
     const uint64_t imask = (1ull << ibits) - 1ull;
     const uint32_t n = io.n, len = io.n - 1u;
@@ -2192,7 +2191,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         }
         if (HEAVY && suspect) {
             const uint32_t left = G <= kTableGroups
-                                      ? resolve_periodic_groups<NT>(alt, cur, a.ncap, m, G, h, rank, io, ibits, gshift, sh)
+                                      ? resolve_periodic_groups<NT>(alt, cur, m, G, h, rank, io, ibits, gshift, sh)
                                       : resolve_short_periodic_groups<NT>(alt, cur, m, h, rank, io, ibits, gshift, period_hint, pc, sh);
             pc.lap(15);
             if (left != m) {
