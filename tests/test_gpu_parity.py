@@ -234,6 +234,9 @@ def test_periodic_runs(orc):
          1 << 20, None),                                                          # text tiled with a long period: many short groups
         (np.concatenate([np.tile(rng.integers(0, 200, size=3000, dtype=np.uint8), 40),
                          np.tile(rng.integers(0, 200, size=5000, dtype=np.uint8), 30)]), 270000, None),  # two long periods
+        (np.tile(rng.integers(0, 200, size=30000, dtype=np.uint8), 20), 1 << 20, None),  # 20 copies: groups beyond the short-group limit
+        (np.tile(np.frombuffer(open(os.path.join(CORPUS, "alice29.txt"), "rb").read()[:70000], np.uint8), 3)[:170000],
+         1 << 20, None),                                                          # two and a bit copies: groups of 2 and 3
         (np.full(50000, ord("a"), np.uint8), 50000, ord("a")),                   # the delimiter continues the run
         (np.tile(np.frombuffer(b"abc", np.uint8), 30000), 90000, ord("a")),
     ]
