@@ -229,6 +229,8 @@ def test_periodic_runs(orc):
                          np.frombuffer(b"q", np.uint8), np.full(50000, 200, np.uint8)]), 1 << 20, None),
         (np.tile(np.frombuffer(b"ba", np.uint8), 70000), 140000, None),
         (np.tile(np.frombuffer(b"abc", np.uint8), 300 * 16384 // 3 + 10), 16384, None),  # more blocks than CUs: 256-thread kernel
+        (np.tile(rng.integers(0, 250, size=5000, dtype=np.uint8), 300 * 32768 // 5000 + 2)[:300 * 32768 + 77], 32768,
+         None),                                                                   # ... with a long period: short groups
         (np.tile(rng.integers(0, 200, size=1000, dtype=np.uint8), 300), 300000, None),   # period 1000: longer than the lane search
         (np.tile(np.frombuffer(open(os.path.join(CORPUS, "alice29.txt"), "rb").read(), np.uint8), 8)[:(1 << 20) + 50000],
          1 << 20, None),                                                          # text tiled with a long period: many short groups
