@@ -1458,6 +1458,7 @@ __device__ __noinline__ void build_next_break(uint32_t* __restrict__ next_break,
 // number of suffixes left (== m: nothing was resolved and `list` is still the list; else the
 // list is now in `spare`).
 constexpr uint32_t kMaxPeriod = 256;  // the break of the period is searched by one lane per group
+constexpr uint32_t kPeriodicMinBlock = 32768;  // shorter blocks never take the periodic-run step
 constexpr uint32_t kFewGroups = 256;     // a round through HBM with at most this many groups: periodic text, most likely
 constexpr uint32_t kTableGroups = 2048;  // more groups than this: no table, one thread walks each (short) group
 constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u, kPeriodMask = 0x00FFFFFFu;
@@ -2045,7 +2046,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     }
     // a bucket with a sixteenth of the block under one key prefix: a dominant key (text has buckets
     // too long for LDS as well, but not of that size; those are sorted through HBM right here)
-    if (!HEAVY && !fused && longest_bucket > n / 16u) {  // workgroup-uniform
+    if (!HEAVY && !fused && longest_bucket > n / 16u && n >= kPeriodicMinBlock) {  // workgroup-uniform
         put_off();
         return;
     }
@@ -2184,7 +2185,8 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         // (long groups are common in the first rounds of plain text, but then there are thousands of groups)
         // ... and a text in which (nearly) every suffix still has a twin after round 0 is repeated text
         const bool all_twins = round == 1 && n - m <= 64u;
-        const bool suspect = full && (stalled || (nchunks == 0 && (G <= kFewGroups || all_twins)));
+        // (short blocks go through their rounds inside LDS faster than the step's sweeps and barriers take)
+        const bool suspect = n >= kPeriodicMinBlock && full && (stalled || (nchunks == 0 && (G <= kFewGroups || all_twins)));
         if (!HEAVY && suspect) {  // workgroup-uniform
             put_off();
             return;
