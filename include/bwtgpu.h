@@ -22,11 +22,10 @@
  *     (reference src/bwt.cpp:131-139); that byte is written by the host layer, not here.
  *   - "_device" entry points take device pointers, enqueue on `stream` (a hipStream_t
  *     passed as void*, NULL = the default stream) and return without synchronising
- *     (bwtgpu_forward_batch_device on a batch of few large blocks, or of blocks above 2 MiB - 1,
- *     is the exception: it reads
- *     small intermediate results back and so blocks the calling thread for most of its
- *     duration; it stays ordered with `stream`); the others take host pointers and are
- *     synchronous.
+ *     (bwtgpu_forward_batch_device on a batch of few large blocks, or of blocks above
+ *     2 MiB - 1, is the exception: it reads small intermediate results back and so blocks
+ *     the calling thread for most of its duration; it stays ordered with `stream`); the
+ *     others take host pointers and are synchronous.
  */
 #ifndef BWTGPU_H
 #define BWTGPU_H
