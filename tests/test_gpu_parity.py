@@ -315,3 +315,29 @@ def test_slab_pipeline_entry_points(orc):
     finally:
         L.bwtgpu_pipeline_destroy(fwd)
         L.bwtgpu_pipeline_destroy(inv)
+
+
+def test_concurrent_callers(orc):
+    """The per-block functions are called from many worker threads in the reference
+    (src/bwt.cpp:143-156): concurrent calls from several host threads give the same bytes."""
+    import threading
+
+    rng = np.random.default_rng(99)
+    inputs = [rng.integers(0, 200, size=int(n), dtype=np.uint8).tobytes()
+              for n in [100, 5000, 30000, 70000, 200000, 1000, 50000, 120000]]
+    want = [orc.forward(d, 255) for d in inputs]
+    got = [None] * len(inputs)
+    back = [None] * len(inputs)
+
+    def work(i):
+        for _ in range(3):
+            got[i] = api.bwt_forward(inputs[i], 255)
+            back[i] = api.bwt_inverse(got[i], 255)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == want
+    assert back == inputs
