@@ -160,24 +160,46 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         Chunking ck;
         ck.init(n, W);
         const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, n);
-        // pass 1: histogram per wave chunk + last delimiter row
+        // pass 1: histogram per wave chunk + last delimiter row.  Order does not matter here, so the
+        // chunk is read a dword per lane (the ranking pass below needs one byte per lane, in row order)
+        constexpr int U = 8;  // vectors whose loads are issued together
         uint32_t last = kNoRow;
-        constexpr int U = 4;  // vectors whose loads are issued together
-        for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave) {
-            uint32_t cs[U];
+        {
+            uint32_t lastp = 0;  // row + 1 of the last delimiter this lane has seen
+            uint32_t* myh = sh.hist + w * 256;
+            auto take = [&](uint32_t c, uint32_t row) {
+                atomicAdd(&myh[c], 1u);
+                if (c == a.delim) lastp = max(lastp, row + 1u);
+            };
+            if (lo < hi) {
+                const uint8_t* p = L + lo;
+                const uint32_t n1 = hi - lo;
+                const uint32_t head = min(n1, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u)) & 3u));
+                const uint32_t nd = (n1 - head) / 4u;
+                const uint32_t* __restrict__ pd = reinterpret_cast<const uint32_t*>(p + head);
+                if ((uint32_t)lane < head) take(p[lane], lo + (uint32_t)lane);
+                for (uint32_t i0 = (uint32_t)lane; i0 < nd; i0 += U * kWave) {
+                    uint32_t d[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) cs[u] = L[min(base0 + (uint32_t)(u * kWave + lane), n - 1u)];
+                    for (int u = 0; u < U; ++u) d[u] = pd[min(i0 + (uint32_t)(u * kWave), nd - 1u)];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t base = base0 + (uint32_t)(u * kWave);
-                if (base < hi) {  // wave-uniform
-                    const bool valid = base + lane < hi;
-                    const uint32_t c = cs[u];
-                    if (valid) atomicAdd(&sh.hist[w * 256 + c], 1u);
-                    const uint64_t isd = __ballot(valid && c == a.delim);
-                    if (isd) last = base + 63u - (uint32_t)__clzll(isd);
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t i = i0 + (uint32_t)(u * kWave);
+                        if (i < nd) {
+                            const uint32_t row = lo + head + 4u * i;
+                            take(d[u] & 255u, row);
+                            take((d[u] >> 8) & 255u, row + 1u);
+                            take((d[u] >> 16) & 255u, row + 2u);
+                            take(d[u] >> 24, row + 3u);
+                        }
+                    }
                 }
+                const uint32_t done = head + 4u * nd;
+                if (done + (uint32_t)lane < n1) take(p[done + (uint32_t)lane], lo + done + (uint32_t)lane);
             }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lastp = max(lastp, (uint32_t)__shfl_xor(lastp, o));
+            if (lastp) last = lastp - 1u;
         }
         if (lane == 0) sh.drow[w] = last;
         __syncthreads();
