@@ -183,9 +183,18 @@ def bwt_forward_process_file(input_file: str, output_file: str, block_size: int)
     except OSError:
         print("Error: Could not open input file " + input_file, file=sys.stderr)
         return 1
-    d = find_unused_byte(raw)
-    if d < 0:
-        print("Error: Cannot find a unique delimiter (all 256 byte values appear in file)", file=sys.stderr)
+    if block_size <= 0:
+        print("Error: Block size must be greater than 0", file=sys.stderr)
+        return 1
+    # transform first, create the output file only once there is something to write
+    try:
+        d = find_unused_byte(raw)
+        if d < 0:
+            print("Error: Cannot find a unique delimiter (all 256 byte values appear in file)", file=sys.stderr)
+            return 1
+        body = forward_batch(raw, block_size, d) if raw.size else b""
+    except BwtGpuError as e:
+        print("Error: " + str(e), file=sys.stderr)
         return 1
     try:
         out = open(output_file, "wb")
@@ -194,8 +203,7 @@ def bwt_forward_process_file(input_file: str, output_file: str, block_size: int)
         return 1
     with out:
         out.write(bytes([d]))
-        if raw.size:
-            out.write(forward_batch(raw, block_size, d))
+        out.write(body)
     return 0
 
 

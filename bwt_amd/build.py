@@ -8,6 +8,7 @@ with a snapshot of the repository to a GPU machine.
 """
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -18,7 +19,6 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libbwtgpu.so")
 SOURCES = ["bwtgpu.hip"]
-HEADERS = ["bwt_device.hpp", "bwt_forward.hpp", "bwt_inverse.hpp"]
 
 
 def _hipcc() -> str:
@@ -32,7 +32,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "bwtgpu.h")]
+    deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+    deps.append(os.path.join(ROOT, "include", "bwtgpu.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,4 +1,4 @@
-// bwt_device.cuh -- shared device-side helpers for the gfx950 BWT kernels.
+// bwt_device.hpp -- shared device-side helpers for the gfx950 BWT kernels.
 //
 // Wavefronts are 64 lanes wide on CDNA4; every cross-lane idiom here (ballot masks,
 // shuffles, lane ids) is written for exactly that width.

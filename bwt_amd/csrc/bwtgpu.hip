@@ -70,13 +70,30 @@ std::vector<Device*> g_dev;
 // Binds device `device` on first use: properties, launch geometry, staging stream.
 int ensure_device(int device);
 
+// Fills the device table (g_mu held).  The table only grows here and is emptied by
+// bwtgpu_shutdown, which must not run while another call is in flight.
+int init_locked(int n_devices) {
+    if (!g_dev.empty()) return (int)g_dev.size();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(BWTGPU_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (n_devices > 0 && n_devices < count) count = n_devices;
+    for (int i = 0; i < count; ++i) g_dev.push_back(new Device);
+    return (int)g_dev.size();
+}
+
 int check_device(int device) {
-    if (g_dev.empty()) {
-        int rc = bwtgpu_init(0);
-        if (rc < 0) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (g_dev.empty()) {
+            int rc = init_locked(0);
+            if (rc < 0) return rc;
+        }
+        if (device < 0 || device >= (int)g_dev.size())
+            return fail(BWTGPU_ERR_NO_DEVICE, "device %d out of range (%d bound)", device, (int)g_dev.size());
     }
-    if (device < 0 || device >= (int)g_dev.size())
-        return fail(BWTGPU_ERR_NO_DEVICE, "device %d out of range (%d bound)", device, (int)g_dev.size());
     return ensure_device(device);
 }
 
@@ -285,6 +302,19 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.t_off = take((size_t)g.tstride * (g.wide ? 8 : 4) * g.nblocks);
     g.bytes = off;
     return g;
+}
+
+// Workspace of a slab pipeline: enough for EVERY batch a slab of `slab_blocks` blocks can be
+// submitted as.  inv_geom is not monotone in the number of blocks -- a batch of fewer than
+// kFewBlocks blocks splits the walk of shorter blocks (segment records, staging and pool: about
+// five times the block bytes), a batch of at most kInvTiledMaxBlocks blocks adds the tile counts --
+// so the maximum is taken over the shapes on either side of each threshold.
+size_t inv_slab_workspace(const Device& d, size_t slab_blocks, size_t block_size) {
+    const size_t chunk = block_size + 1;
+    size_t most = 0;
+    for (size_t nb : {slab_blocks, std::min(slab_blocks, (size_t)kFewBlocks - 1), std::min(slab_blocks, kInvTiledMaxBlocks)})
+        if (nb) most = std::max(most, inv_geom(d, nb * chunk, block_size).bytes);
+    return most;
 }
 
 // ---- delimiter search --------------------------------------------------------
@@ -551,6 +581,7 @@ struct PipeSlot {
     uint8_t* d_out = nullptr;
     uint32_t* d_lens = nullptr;
     void* d_ws = nullptr;
+    size_t ws_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     size_t in_bytes = 0;
@@ -601,6 +632,7 @@ int pipeline_alloc(bwtgpu_pipeline* p, int depth) {
         HIP_TRY(hipMalloc((void**)&s.d_out, p->out_cap));
         HIP_TRY(hipMalloc((void**)&s.d_lens, (p->slab_blocks + 8) * 4));
         HIP_TRY(hipMalloc(&s.d_ws, p->ws_bytes));
+        s.ws_cap = p->ws_bytes;
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
@@ -616,15 +648,7 @@ const char* bwtgpu_last_error(void) { return g_err; }
 
 int bwtgpu_init(int n_devices) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_dev.empty()) return (int)g_dev.size();
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return fail(BWTGPU_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
-                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-    if (n_devices > 0 && n_devices < count) count = n_devices;
-    for (int i = 0; i < count; ++i) g_dev.push_back(new Device);
-    return (int)g_dev.size();
+    return init_locked(n_devices);
 }
 
 void bwtgpu_shutdown(void) {
@@ -642,7 +666,10 @@ void bwtgpu_shutdown(void) {
     g_dev.clear();
 }
 
-int bwtgpu_device_count(void) { return (int)g_dev.size(); }
+int bwtgpu_device_count(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    return (int)g_dev.size();
+}
 
 size_t bwtgpu_num_blocks(size_t total_len, size_t block_size) {
     return block_size ? (total_len + block_size - 1) / block_size : 0;
@@ -1005,7 +1032,7 @@ bwtgpu_pipeline* bwtgpu_pipeline_create(int device, int direction, size_t block_
     } else {
         p->in_cap = slab_blocks * (block_size + 1);
         p->out_cap = slab_blocks * block_size;
-        p->ws_bytes = inv_geom(d, p->in_cap, block_size).bytes;
+        p->ws_bytes = inv_slab_workspace(d, slab_blocks, block_size);
     }
     if (pipeline_alloc(p, depth) != BWTGPU_OK) {
         pipeline_free(p);
@@ -1032,18 +1059,30 @@ int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t d
     const bool uploaded = bytes && s.resident == bytes;
     s.resident = 0;
     if (bytes) {
+        // The slot's workspace was sized for every shape a slab can take; should a batch still ask
+        // for more, the slot gets a larger one rather than failing.
+        const size_t need = p->direction == BWTGPU_FORWARD ? bwtgpu_forward_workspace_bytes(p->device, bytes, p->block_size)
+                                                           : bwtgpu_inverse_workspace_bytes(p->device, bytes, p->block_size);
+        if (need > s.ws_cap) {
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            HIP_TRY(hipFree(s.d_ws));
+            s.d_ws = nullptr;
+            s.ws_cap = 0;
+            HIP_TRY(hipMalloc(&s.d_ws, need));
+            s.ws_cap = need;
+        }
         if (!uploaded) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
         int rc;
         if (p->direction == BWTGPU_FORWARD) {
             rc = bwtgpu_forward_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_ws,
-                                             p->ws_bytes, s.stream);
+                                             s.ws_cap, s.stream);
             if (rc) return rc;
             const size_t nb = (bytes + p->block_size - 1) / p->block_size;
             HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, bytes + nb, hipMemcpyDeviceToHost, s.stream));
             HIP_TRY(hipMemcpyAsync(s.h_lens, s.d_ws, 8, hipMemcpyDeviceToHost, s.stream));
         } else {
             rc = bwtgpu_inverse_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_lens,
-                                             s.d_ws, p->ws_bytes, s.stream);
+                                             s.d_ws, s.ws_cap, s.stream);
             if (rc) return rc;
             const size_t nb = (bytes + p->block_size) / (p->block_size + 1);
             if (bytes > nb) HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, bytes - nb, hipMemcpyDeviceToHost, s.stream));

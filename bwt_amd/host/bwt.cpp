@@ -3,6 +3,7 @@
 #include "bwt.hpp"
 
 #include <cstdint>
+#include <cstdio>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -57,11 +58,22 @@ std::string bwt_forward(const std::string& input, char delimiter) {
     return out;
 }
 
+// Whether the file can be opened for reading, without a message: the shortcuts below stay silent
+// about a missing input so that the general route reports it exactly once, as the reference does
+// (its find_unique_char opens the file first, src/bwt.cpp:23-26, and the constructor at
+// src/file_processor.cpp:7-10 prints the message).
+static bool readable(const char* path) {
+    std::FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fclose(f);
+    return true;
+}
+
 // A regular file that fits one slab is read and uploaded ONCE: the delimiter search runs on the
 // uploaded bytes and the transform then starts from them.  Returns -1 when the file does not
 // qualify (the caller then takes the general two-pass route), else the result code.
 static int forward_single_slab(const char* input_file, const char* output_file, size_t block_size) {
-    if (block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE) return -1;
+    if (block_size == 0 || block_size > BWTGPU_MAX_BLOCK_SIZE || !readable(input_file)) return -1;
     FileProcessor reader(input_file, "", block_size);
     if (!reader.is_open() || !reader.input_is_regular() || reader.input_size() == 0) return -1;
     const size_t size = reader.input_size();
@@ -117,7 +129,7 @@ static int forward_single_slab(const char* input_file, const char* output_file, 
 }
 
 int bwt_forward_process_file(const char* input_file, const char* output_file, size_t block_size) {
-    if (block_size > BWTGPU_MAX_BLOCK_SIZE) {
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE && readable(input_file)) {
         // A block size beyond the file makes the file one block of its own length; only a file
         // that really has to be cut into blocks longer than the library's limit is refused (later).
         FileProcessor probe(input_file, "", 1);

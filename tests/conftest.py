@@ -34,3 +34,8 @@ def corpus_golden():
 @pytest.fixture(scope="session")
 def synthetic_golden():
     return load_golden("synthetic.json")
+
+
+@pytest.fixture(scope="session")
+def mixed_golden():
+    return load_golden("mixed.json")

@@ -19,6 +19,11 @@ data only:
                           (benchmark configuration 1), in full.
 * synthetic.json       -- reference forward outputs (SHA-256; in full for short blocks) for
                           seeded synthetic blocks of every generator kind.
+* mixed.json           -- the mixed corpus (1 MiB segments cycling random255 / ACGT / period-7 /
+                          tiled alice29.txt) at 1 MiB blocks: per-block SHA-256 of the reference's
+                          forward output for spans that give every segment kind a block of its own,
+                          a ragged tail, and a span whose blocks straddle two segments.
+                          ``python tests/golden/make_golden.py --only mixed`` regenerates just it.
 """
 import hashlib
 import json
@@ -69,8 +74,39 @@ def sha(b: bytes) -> str:
     return hashlib.sha256(b).hexdigest()
 
 
+# (offset, length) spans of the mixed stream, all at 1 MiB blocks: four whole segments + a ragged
+# tail from a segment boundary (blocks = segments: random255, ACGT, period-7, text, random255 tail);
+# the same from another place in the stream (other text phase); blocks that straddle two segments.
+MIXED_SPANS = [(0, 4 * (1 << 20) + 300000), (37 * (1 << 20), 4 * (1 << 20) + 77), ((1 << 20) + 500000, 3 * (1 << 20) + 1234)]
+
+
+def mixed_rows(ref):
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    seed = synth.base_seed(5)
+    bs = 1 << 20
+    rows = []
+    for offset, length in MIXED_SPANS:
+        data = synth.generate("mixed", seed, offset, length, text=text).tobytes()
+        present = set(data)
+        delim = next(v for v in range(256) if v not in present)
+        blocks = []
+        for b0 in range(0, length, bs):
+            blk = data[b0:b0 + bs]
+            fwd = ref.forward(blk, delim)
+            assert ref.inverse(fwd, delim) == blk
+            blocks.append(sha(fwd))
+        rows.append({"kind": "mixed", "seed": seed, "offset": offset, "length": length, "block_size": bs,
+                     "delimiter": delim, "input_sha256": sha(data), "block_forward_sha256": blocks})
+    return rows
+
+
 def main() -> None:
     ref = oracle.reference()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "mixed":
+        with open(os.path.join(HERE, "mixed.json"), "w") as f:
+            json.dump(mixed_rows(ref), f, indent=1)
+        print("wrote mixed.json")
+        return
 
     known = []
     for name, data, delim, expect in KNOWN:
@@ -144,6 +180,8 @@ def main() -> None:
             synthetic.append(row)
     with open(os.path.join(HERE, "synthetic.json"), "w") as f:
         json.dump(synthetic, f, indent=1)
+    with open(os.path.join(HERE, "mixed.json"), "w") as f:
+        json.dump(mixed_rows(ref), f, indent=1)
     print("wrote", len(known), "known answers,", len(corpus), "corpus rows,", len(synthetic), "synthetic rows")
 
 

@@ -62,7 +62,10 @@ def test_cli_contract(tmp_path):
         r = run([exe, "a", "b", "0"])
         assert r.returncode == 1 and "Block size must be greater than 0" in r.stderr
         r = run([exe, str(tmp_path / "missing"), str(tmp_path / "o")])
-        assert r.returncode == 1 and "Could not open input file" in r.stderr
+        assert r.returncode == 1 and r.stderr.count("Could not open input file") == 1
+        # the forward tool then reports what the reference reports (src/bwt.cpp:163-166): its
+        # delimiter search could not read the file
+        assert ("Cannot find a unique delimiter" in r.stderr) == (exe == bwt)
     # default block size is 128 bytes (reference src/bwt.cpp:249, src/inverse_bwt.cpp:111)
     src = os.path.join(CORPUS, "grammar.lsp")
     f, b = str(tmp_path / "g.bwt"), str(tmp_path / "g.out")
@@ -117,3 +120,87 @@ def test_two_slab_pipeline_depth(tmp_path):
         assert got == want, blk
     assert run([os.path.join(BUILD, "inverse_bwt"), f, b, "512"]).returncode == 0
     assert np.array_equal(np.fromfile(b, dtype=np.uint8), data)
+
+
+def _sample_blocks_equal_oracle(data, out, bs, delim, blocks):
+    import oracle
+
+    orc = oracle.oracle()
+    for blk in blocks:
+        want = orc.forward(data[blk * bs:(blk + 1) * bs].tobytes(), delim)
+        got = out[1 + blk * (bs + 1):1 + blk * (bs + 1) + len(want)].tobytes()
+        assert got == want, (bs, blk)
+
+
+# Block sizes on either side of every threshold at which the library changes kernels or workspace
+# layout (one-wave blocks up to 1024 bytes, walks split from 1280 / 4096 rows, tiled table build
+# from 16384 rows, device-wide forward path from 20000 bytes), with block counts just below 128 and
+# just below 2048, where the batch geometry changes; the last block is ragged.
+@pytest.mark.parametrize("bs", [1025, 1279, 1280, 2048, 3000, 4095, 16383, 19999, 20000])
+@pytest.mark.parametrize("nblocks", [127, 2047])
+def test_cli_round_trip_around_geometry_thresholds(tmp_path, bs, nblocks):
+    import numpy as np
+
+    from bwt_amd import synth
+
+    total = (nblocks - 1) * bs + bs // 3 + 1
+    data = synth.generate("random255", 77 + bs, 0, total)
+    data[data > 200] = 65  # a skewed byte: longer doubling, and the delimiter is 201
+    src, f, b = str(tmp_path / "in"), str(tmp_path / "f.bwt"), str(tmp_path / "out")
+    data.tofile(src)
+    r = run([os.path.join(BUILD, "bwt"), src, f, str(bs)])
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(f, dtype=np.uint8)
+    assert out.size == total + 1 + nblocks and out[0] == 201
+    _sample_blocks_equal_oracle(data, out, bs, 201, [0, 1, nblocks // 2, nblocks - 2, nblocks - 1])
+    r = run([os.path.join(BUILD, "inverse_bwt"), f, b, str(bs)])
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(b, dtype=np.uint8), data)
+
+
+@pytest.mark.parametrize("bs,slab", [(1279, 2048), (1280, 2048), (2048, 2048), (4095, 2048), (16383, 256),
+                                     (19999, 256), (20000, 256)])
+def test_pipeline_sized_for_a_full_slab_takes_any_shorter_batch(bs, slab):
+    """A pipeline is created once for a full slab and then handed shorter batches (the last slab
+    of a file, or a smaller file that reuses a cached pipeline): batches on either side of every
+    block-count threshold must fit its workspace and give the oracle's bytes."""
+    import ctypes
+
+    import numpy as np
+
+    import oracle
+    from bwt_amd import api, synth
+
+    L = api.lib()
+    assert api.init(1) >= 1
+    orc = oracle.oracle()
+    data = synth.generate("random255", 5 + bs, 0, slab * bs)
+    data[data > 180] = 66
+    delim = 181
+    fwd = L.bwtgpu_pipeline_create(0, 0, bs, slab, 1)
+    inv = L.bwtgpu_pipeline_create(0, 1, bs, slab, 1)
+    assert fwd and inv, api.last_error()
+    try:
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        counts = sorted({1, 31, 32, 33, 127, 128, 129, slab - 1, slab} | ({821, 822, 1465, 2047} if slab >= 2048 else set()))
+        for nb in counts:
+            for ragged in (0, bs // 2):
+                total = nb * bs - ragged
+                if total <= 0:
+                    continue
+                ctypes.memmove(L.bwtgpu_pipeline_input(fwd, 0), data.ctypes.data, total)
+                assert L.bwtgpu_pipeline_submit(fwd, 0, total, delim) == 0, (nb, api.last_error())
+                assert L.bwtgpu_pipeline_collect(fwd, 0, ctypes.byref(out), ctypes.byref(n)) == 0, (nb, api.last_error())
+                got = np.frombuffer(ctypes.string_at(out.value, n.value), dtype=np.uint8)
+                assert got.size == total + nb
+                for blk in {0, nb // 2, nb - 1}:
+                    want = orc.forward(data[blk * bs:min((blk + 1) * bs, total)].tobytes(), delim)
+                    assert got[blk * (bs + 1):blk * (bs + 1) + len(want)].tobytes() == want, (bs, nb, blk)
+                ctypes.memmove(L.bwtgpu_pipeline_input(inv, 0), got.ctypes.data, got.size)
+                assert L.bwtgpu_pipeline_submit(inv, 0, got.size, delim) == 0, (nb, api.last_error())
+                assert L.bwtgpu_pipeline_collect(inv, 0, ctypes.byref(out), ctypes.byref(n)) == 0, (nb, api.last_error())
+                assert n.value == total
+                assert ctypes.string_at(out.value, total) == data[:total].tobytes(), (bs, nb)
+    finally:
+        L.bwtgpu_pipeline_destroy(fwd)
+        L.bwtgpu_pipeline_destroy(inv)

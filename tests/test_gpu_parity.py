@@ -177,6 +177,49 @@ def test_benchmark_shapes_against_oracle(orc, kind, bs):
     assert api.inverse_batch(got, bs, delim) == data
 
 
+def test_synth_device_matches_host_generator():
+    """The device generator bench.py fills HBM with writes exactly the bytes of synth.generate:
+    every kind, unaligned offsets and lengths, spans that cross mixed-corpus segment borders."""
+    import ctypes
+
+    import torch
+
+    L = api.lib()
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    dev = torch.device("cuda", 0)
+    d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    spans = [(0, 1), (3, 4099), (1 << 20, 65536), ((1 << 20) - 7, 100003), (5 * (1 << 20) - 123457, 3 * (1 << 20) + 11),
+             ((1 << 32) - 1000, 70001), (7 * (1 << 30) + 13, 262144 + 5)]
+    for kind, code in synth.KINDS.items():
+        for seed in (synth.base_seed(2), synth.base_seed(5), 12345):
+            for offset, length in spans:
+                want = synth.generate(kind, seed, offset, length, text=text)
+                d_out = torch.full((length + 64,), 0xEE, dtype=torch.uint8, device=dev)
+                api.check(L.bwtgpu_synth_device(0, code, seed, offset, ctypes.c_void_p(d_out.data_ptr() + 32), length,
+                                                ctypes.c_void_p(d_text.data_ptr()), d_text.numel(), None))
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy()
+                assert np.array_equal(got[32:32 + length], want), (kind, seed, offset, length)
+                assert (got[:32] == 0xEE).all() and (got[32 + length:] == 0xEE).all(), (kind, offset, length)
+
+
+def test_mixed_corpus_against_reference(mixed_golden):
+    """BASELINE's mixed corpus at 1 MiB blocks: every segment kind fills a block (uniform bytes, ACGT,
+    period-7 and tiled text at 1 MiB), ragged tails, blocks that straddle two segments -- per-block
+    SHA-256 of the forward bytes equal the reference's, and the inverse restores the input."""
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    for row in mixed_golden:
+        data = synth.generate("mixed", row["seed"], row["offset"], row["length"], text=text).tobytes()
+        assert hashlib.sha256(data).hexdigest() == row["input_sha256"]
+        bs, delim = row["block_size"], row["delimiter"]
+        assert api.find_unused_byte(data) == delim
+        got = api.forward_batch(data, bs, delim)
+        for i, want in enumerate(row["block_forward_sha256"]):
+            blk = got[i * (bs + 1):(i + 1) * (bs + 1)]
+            assert hashlib.sha256(blk).hexdigest() == want, (row["offset"], i)
+        assert api.inverse_batch(got, bs, delim) == data, row["offset"]
+
+
 def test_skewed_distributions_and_many_blocks(orc):
     """Inputs that stress the round-0 bucket partition (one dominant key range that does not fit an
     LDS bucket, sparse key space, runs of equal bytes) and a batch whose block count is not a

@@ -96,6 +96,19 @@ def test_synthetic_vectors(orc, synthetic_golden):
         assert orc.inverse(fwd, row["delimiter"]) == data
 
 
+def test_mixed_corpus_vectors(orc, mixed_golden):
+    """The mixed corpus at 1 MiB blocks: the oracle reproduces the reference's per-block bytes."""
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    row = mixed_golden[0]
+    data = synth.generate("mixed", row["seed"], row["offset"], row["length"], text=text).tobytes()
+    assert hashlib.sha256(data).hexdigest() == row["input_sha256"]
+    bs = row["block_size"]
+    out = orc.forward_buffer(data, bs, 8)
+    assert out[0] == row["delimiter"]
+    for i, want in enumerate(row["block_forward_sha256"]):
+        assert hashlib.sha256(out[1 + i * (bs + 1):1 + (i + 1) * (bs + 1)]).hexdigest() == want, i
+
+
 def test_file_drivers(orc, tmp_path):
     src = os.path.join(CORPUS, "fields.c")
     raw = open(src, "rb").read()
