@@ -1,14 +1,15 @@
 #!/bin/bash
 # Produces the per-round profile artefacts on the GPU box (run through gpurun):
 #   kernel stats (rocprofv3 --kernel-trace --stats) and HBM traffic (two separate --pmc runs).
-# usage: tools/profile_round.sh <tag>     e.g. r01_v7
+# usage: tools/profile_round.sh <tag> [workload]     e.g. r02_v1 mixed-4g-1m
 tag=${1:-rXX}
-out=gpurun_out/prof_$tag
+wl=${2:-acgt-4g-256k}
+out=gpurun_out/prof_${tag}_$wl
 mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --workload $wl"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- $B > $out/stats.log 2>&1 || { echo stats failed; tail -5 $out/stats.log; exit 1; }
-B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads"
+B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads --workload $wl"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch --output-format csv -- $B1 > $out/fetch.log 2>&1 || { echo fetch failed; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write --output-format csv -- $B1 > $out/write.log 2>&1 || { echo write failed; exit 1; }
 python - <<PY
