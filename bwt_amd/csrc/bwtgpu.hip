@@ -33,6 +33,14 @@ constexpr size_t kInvTiledMinRows = 16384;   // ... of at least this many rows b
 
 thread_local char g_err[512] = "";
 
+// Scratch of bwtgpu_forward_batch_static, the entry point that allocates nothing: every GPU the
+// library runs on holds its own copy of this array from the moment the code object is loaded until
+// the process ends.  Host code never uses the array's name as an address -- it is a host-side
+// stand-in there; ensure_device asks the runtime for each device's copy (hipGetSymbolAddress)
+// and everything below goes through that pointer (Device::static_ws).
+constexpr size_t kStaticScratchBytes = BWTGPU_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -59,6 +67,8 @@ struct Device {
     void* d_ws = nullptr;   size_t ws_cap = 0;
     void* d_aux = nullptr;  size_t aux_cap = 0;
     hipStream_t stream = nullptr;
+    uint8_t* static_ws = nullptr;  // this device's copy of `scratch` (nullptr: the lookup failed, see static_ws_error)
+    hipError_t static_ws_error = hipSuccess;
     bool ready = false;
     std::mutex mu;          // one host-pointer call at a time per device
     std::mutex init_mu;     // guards first-use binding
@@ -423,6 +433,10 @@ int ensure_device(int device) {
             hipSuccess && occ > 0)
         d->inv_wgs_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    // this device's copy of the static scratch array (the device is current here)
+    void* sp = nullptr;
+    d->static_ws_error = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+    d->static_ws = d->static_ws_error == hipSuccess ? (uint8_t*)sp : nullptr;
     d->ready = true;
     return BWTGPU_OK;
 }
@@ -572,6 +586,40 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     return BWTGPU_OK;
 }
 
+// ---- forward, one workgroup per block: launches over a workspace laid out as header, g.grid
+// slices of g.stride bytes, list of put-off blocks ---------------------------------------------
+int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_t total_len, size_t block_size,
+                   uint8_t delimiter, uint8_t* d_out, uint8_t* ws, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(ws, 0, kHeaderBytes, s));
+    FwdArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.total_len = total_len;
+    a.block_size = (uint32_t)block_size;
+    a.nblocks = (uint32_t)g.nblocks;
+    a.ncap = g.ncap;
+    a.delim = delimiter;
+    a.ws = ws + kHeaderBytes;
+    a.ws_stride = g.stride;
+    a.queue = (uint32_t*)ws;
+    a.deferred = (uint32_t*)(ws + kHeaderBytes + g.stride * g.grid);
+    if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
+        const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
+        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
+        hipLaunchKernelGGL(bwt_forward_small_kernel, dim3(grid), dim3(kSmallWaves * kWave), 0, s, a);
+    } else if (g.wide) {
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, false>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, true>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 1);
+    } else {
+        // the common case first; the blocks it puts off (periodic runs, dominant keys) in a second
+        // launch of the full kernel, which finds an empty list otherwise
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, true>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return BWTGPU_OK;
+}
+
 // ---- slab pipeline ------------------------------------------------------------
 struct PipeSlot {
     uint8_t* h_in = nullptr;
@@ -710,37 +758,53 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     if (g.nblocks > 0xFFFFFFF0ull) return fail(BWTGPU_ERR_INVALID, "too many blocks in one batch");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
-    FwdArgs a;
-    a.in = d_in;
-    a.out = d_out;
-    a.total_len = total_len;
-    a.block_size = (uint32_t)block_size;
-    a.nblocks = (uint32_t)g.nblocks;
-    a.ncap = g.ncap;
-    a.delim = delimiter;
-    a.ws = (uint8_t*)d_workspace + kHeaderBytes;
-    a.ws_stride = g.stride;
-    a.queue = (uint32_t*)d_workspace;
-    a.deferred = (uint32_t*)((uint8_t*)d_workspace + kHeaderBytes + g.stride * g.grid);
-    if (g.grid_path) return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
+    if (g.grid_path) {
+        HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
+        return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
+    }
     if (block_size > kBlockKernelMaxBlock)
         return fail(BWTGPU_ERR_INVALID, "a batch of blocks above %zu bytes may hold at most 2^31 bytes (%zu given): split it",
                     kBlockKernelMaxBlock, total_len);
-    if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
-        const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
-        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
-        hipLaunchKernelGGL(bwt_forward_small_kernel, dim3(grid), dim3(kSmallWaves * kWave), 0, s, a);
-    } else if (g.wide) {
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, false>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 0);
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, true>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 1);
-    } else {
-        // the common case first; the blocks it puts off (periodic runs, dominant keys) in a second
-        // launch of the full kernel, which finds an empty list otherwise
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 0);
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, true>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 1);
+    return forward_blocks(d, g, d_in, total_len, block_size, delimiter, d_out, (uint8_t*)d_workspace, s);
+}
+
+int bwtgpu_forward_batch_static(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                uint8_t delimiter, uint8_t* d_out, uint32_t* d_status, void* stream) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    block_size = forward_block_size(total_len, block_size);
+    if (block_size > kBlockKernelMaxBlock)
+        return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds what the static scratch serves (%zu)", block_size,
+                    kBlockKernelMaxBlock);
+    const Device& d = *g_dev[device];
+    if (!d.static_ws)
+        return fail(BWTGPU_ERR_HIP, "hipGetSymbolAddress of the static scratch failed on device %d: %s", device,
+                    hipGetErrorString(d.static_ws_error));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(device));
+    if (total_len == 0) {
+        if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(uint32_t), s));
+        return BWTGPU_OK;
     }
-    HIP_TRY(hipGetLastError());
+    if (!d_in || !d_out) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+    // The one-workgroup-per-block kernels with as many workgroups as the fixed scratch holds slices
+    // for (a slice is 20 bytes per block byte); the workgroups pull blocks from a queue, so fewer of
+    // them only means less of the chip is used.
+    FwdGeom g = fwd_geom(d, total_len, block_size);
+    if (g.nblocks > 0xFFFFFFF0ull) return fail(BWTGPU_ERR_INVALID, "too many blocks in one batch");
+    const size_t fixed = kHeaderBytes + round_up(g.nblocks * 4, 256);
+    const size_t slices = fixed < kStaticScratchBytes ? (kStaticScratchBytes - fixed) / g.stride : 0;
+    if (slices == 0)
+        return fail(BWTGPU_ERR_WORKSPACE,
+                    "batch of %zu blocks of %zu bytes exceeds the static scratch of %zu bytes (needs %zu for its block list "
+                    "and %zu per resident block)", g.nblocks, block_size, kStaticScratchBytes, fixed, g.stride);
+    g.grid = (uint32_t)std::min<size_t>(g.grid, slices);
+    g.wide = g.grid <= (uint32_t)d.cus && std::min(total_len, block_size) >= kWideMinBlock;
+    g.grid_path = false;
+    rc = forward_blocks(d, g, d_in, total_len, block_size, delimiter, d_out, d.static_ws, s);
+    if (rc) return rc;
+    if (d_status) HIP_TRY(hipMemcpyAsync(d_status, d.static_ws + 4, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     return BWTGPU_OK;
 }
 

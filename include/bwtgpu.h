@@ -90,6 +90,23 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
 int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t block_size,
                          uint8_t delimiter, uint8_t* out);
 
+/* ---- forward with no allocation anywhere (no counterpart in the reference) -----------------
+ * For callers that cannot allocate device memory or be handed a workspace: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same transform and same bytes as
+ * bwtgpu_forward_batch_device, but the scratch is a fixed array of BWTGPU_STATIC_SCRATCH_BYTES that
+ * lives in the library's code object on every GPU (each GPU holds its copy until the process ends),
+ * and the call itself allocates nothing, on host or device.  Limits: block_size (after clamping to
+ * the batch) at most 2 MiB - 1 (BWTGPU_ERR_BLOCK_TOO_LARGE), and the batch's block list (4 bytes per
+ * block) plus one block's slice (20 bytes per block byte) must fit the array (BWTGPU_ERR_WORKSPACE).
+ * Throughput is lower than with a caller-sized workspace: only as many blocks are in flight as
+ * slices fit (49 at 64 KiB blocks, 12 at 256 KiB, 3 at 1 MiB); batches of few large blocks do not
+ * take the device-wide path.  All calls on one GPU share the array: calls that overlap on one GPU
+ * (different streams or threads) race -- serialise them.  d_status (device memory, may be NULL)
+ * receives the kernels' error flags (0 = none) once the stream reaches that point. */
+#define BWTGPU_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
+int bwtgpu_forward_batch_static(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                uint8_t delimiter, uint8_t* d_out, uint32_t* d_status, void* stream);
+
 /* ---- inverse: replaces the serial loop of reference src/inverse_bwt.cpp:85-95 and
  *      bwt_inverse (src/inverse_bwt.cpp:13-63) for a whole batch of blocks ------
  * `in` is the concatenation of (len_i + 1)-byte transformed blocks, i.e. chunks of
