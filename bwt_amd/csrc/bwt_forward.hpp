@@ -84,7 +84,8 @@ constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition a
 // write-back), 11 round-0 bucket sorts through HBM, 12 round-0 bucket sorts in LDS, 13 / 14 later
 // rounds' chunk sorts / chunk reranks in LDS, 15 periodic-run resolution (of which, for lists of
 // many short groups: 16 the vote, 17 the next-break table, 18 the settling sweep; the rest of 15 is
-// the compaction and the table variant).
+// the compaction and the table variant), 19 the search for a whole-block period, 20 the expansion of
+// a periodic block's output from its last two periods.
 struct PhaseClock {
     unsigned long long t;
     unsigned long long* acc;
@@ -134,6 +135,8 @@ struct FwdShared {
     unsigned long long vote;        // periodic runs: members << 32 | step of the most populous long step
     uint32_t tailrow[kMaxM0 + 1];   // final rows of the suffixes that reach the delimiter within m0 symbols
     uint32_t blk;
+    uint32_t period_cand;           // whole-block period: first place the block's first 16 bytes occur again
+    uint32_t period_bad;            // ... and whether the text fails to repeat at that distance somewhere
 };
 
 template <int NT>
@@ -1020,7 +1023,8 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
 // sorted positions s0 .. s0+cnt-1; a bucket is a key range, so runs never cross its ends):
 // writes the bucket back to g, stores the output byte of every suffix that is alone in its run,
 // and for the others writes rank (= global position of the run's first element) and appends
-// (dense group id << gshift | index) to nxt.  m_tot / g_tot are the running survivor and group
+// (dense group id << gshift | index) to nxt (all_ranks: the finished suffixes get their rank -- their
+// row -- as well).  m_tot / g_tot are the running survivor and group
 // counts of the block and are advanced.  The elements in LDS are still shifted left by `up`
 // and lack `bsub` (see lds_sort_bucket).  A first sweep finds the run heads and tails of every
 // 64-element vector (kept as ballots in v.cw) and counts; the second one acts on them.
@@ -1028,8 +1032,8 @@ template <int NT>
 __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t s0, uint32_t cnt,
                                               uint64_t* __restrict__ nxt, uint32_t* __restrict__ rank,
                                               uint8_t* __restrict__ out, int ibits, int kshift, int gshift,
-                                              int up, uint64_t bsub, FwdShared<NT>& sh, uint32_t& m_tot,
-                                              uint32_t& g_tot) {
+                                              int up, uint64_t bsub, bool all_ranks, FwdShared<NT>& sh,
+                                              uint32_t& m_tot, uint32_t& g_tot) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
     const uint64_t* ls = sh.u.lsort;
@@ -1132,6 +1136,7 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
                     const uint32_t idx = (uint32_t)(ec & imask);
                     if (valid) g[k] = ec;
                     if (single) out[s0 + k] = (uint8_t)(ec >> ibits);
+                    if (all_ranks && single) rank[idx] = s0 + k;
                     if (act) {
                         rank[idx] = s0 + khead;
                         const uint32_t pos = baseA + __popcll(A & lt);
@@ -1467,7 +1472,7 @@ template <int NT>
 __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restrict__ list, uint64_t* spare,
                                                             uint32_t m, uint32_t G, uint32_t h,
                                                             uint32_t* __restrict__ rank, const BlockIO& io, int ibits,
-                                                            int gshift, FwdShared<NT>& sh) {
+                                                            int gshift, bool keep_ranks, FwdShared<NT>& sh) {
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     static_assert(FwdShared<NT>::kSortCap * 2 >= 4 * (int)kTableGroups, "the group table lives in the LDS sort buffer");
@@ -1611,7 +1616,7 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
     // (member a of a group sits at min + a p and goes to row first + a or first + count - 1 - a:
     // consecutive rows, evenly strided text and rank accesses) rather than in list order.
     const bool by_group = G <= 64u;
-    const bool later = resolved < m;  // suffixes remain: their next keys will look these ranks up
+    const bool later = resolved < m || keep_ranks;  // suffixes remain: their next keys will look these ranks up (or the caller wants every final rank)
     if (by_group) {
 #pragma unroll 1
         for (uint32_t g = 0; g < G; ++g) {
@@ -1628,7 +1633,7 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
             }
         }
     }
-    if (by_group && !later) {  // nothing to carry on
+    if (by_group && resolved == m) {  // nothing to carry on
         __syncthreads();
         return 0;
     }
@@ -1930,12 +1935,195 @@ __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restr
     return m - resolved;
 }
 
+// ---- blocks that are periodic as a whole ----------------------------------------------------------
+// A block whose text has period P throughout (text[i] == text[i - P] for all i >= P; P the SMALLEST
+// such distance, 3 P <= len) does not need all its suffixes sorted.  Let T2 be the block's last 2 P
+// symbols plus the delimiter.  T2's suffixes ARE the block's suffixes at positions >= len - 2 P, so
+// sorting T2 orders them.  Every other suffix i lies on the chain j, j - P, j - 2 P, ... of exactly
+// one suffix j in T2's first period (len - 2 P <= j < len - P).  Two members of a chain agree until
+// the later one reaches the delimiter, where the earlier one has the symbol text[len - P]: the whole
+// chain is ordered by position, descending if the delimiter is the smaller of the two and ascending
+// otherwise (the same for every chain).  And nothing else falls between two members: it would have
+// to share their first P symbols, which -- P being the smallest period, so that no two of the P
+// rotations of a period are equal -- only suffixes at the same position modulo P do.  So the block's
+// suffix array is T2's with every first-period suffix replaced by its chain, and the output is
+// T2's sorted order written out run by run: a chain's members all have the same preceding byte
+// (except the suffix at position 0, which has the delimiter).
+// period-7 text in 256 KiB blocks: 15 suffixes are sorted instead of 262 145; text tiled 6.9 times
+// in a 1 MiB block: 304 K instead of 1 M.
+
+// The smallest whole-block period P with 3 P <= len, or 0.  The candidate is the first place where
+// the block's first 16 bytes occur again (any period is such a place, so the first one that holds
+// for the whole block is the smallest period; only that first place is tried).
+template <int NT>
+__device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__ s, uint32_t len, const uint8_t* g_lo,
+                                                      const uint8_t* g_hi, FwdShared<NT>& sh) {
+    const int tid = threadIdx.x;
+    if (len < 64u) return 0;  // workgroup-uniform
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3u);
+    const uint8_t* ab = s - mis;  // dword-aligned; block position i is byte i + mis from here
+    if (tid == 0) {
+        sh.period_cand = 0xFFFFFFFFu;
+        sh.period_bad = 0;
+    }
+    __syncthreads();
+    const uint32_t pat0 = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    const uint32_t limit = len / 3u;  // candidates 1 .. limit
+    constexpr int U = 4;  // dword pairs whose loads are issued together
+    const uint32_t nq = (limit + mis) / 4u + 1u;
+#pragma unroll 1
+    for (uint32_t q0 = (uint32_t)tid; q0 < nq; q0 += U * NT) {
+        uint32_t w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * NT);
+            w0[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
+            w1[u] = load_dword_guarded(ab + 4u * (uint64_t)q + 4u, g_lo, g_hi);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * NT);
+#pragma unroll
+            for (uint32_t o = 0; o < 4u; ++o) {
+                const uint32_t v = o == 0 ? w0[u] : __builtin_amdgcn_alignbyte(w1[u], w0[u], o);
+                const uint32_t at = 4u * q + o;  // byte offset from ab
+                if (v == pat0 && at > mis && at - mis <= limit) {
+                    const uint32_t i = at - mis;
+                    bool same = true;
+                    for (uint32_t k = 4; k < 16u; ++k) same = same && s[i + k] == s[k];  // i + 16 <= len / 3 + 16 <= len
+                    if (same) atomicMin(&sh.period_cand, i);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t P = sh.period_cand;
+    if (P == 0xFFFFFFFFu) return 0;  // workgroup-uniform
+    // does the text repeat at distance P everywhere?  aligned dwords of the upper copy against the
+    // bytes P below them (two aligned dwords and a funnel shift: the misalignment is the same everywhere)
+    const uint32_t m2 = (0u - P) & 3u;
+    const uint32_t q_lo = (P + mis) / 4u, q_hi = (len + mis + 3u) / 4u;  // dwords that hold positions P .. len-1
+    bool bad = false;
+#pragma unroll 1
+    for (uint32_t q0 = q_lo + (uint32_t)tid; q0 < q_hi; q0 += U * NT) {
+        uint32_t a[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * NT);
+            const int64_t bo = (int64_t)4 * q - (int64_t)P - (int64_t)m2;  // aligned byte offset of the lower dword pair
+            a[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
+            b0[u] = load_dword_guarded(ab + bo, g_lo, g_hi);
+            b1[u] = load_dword_guarded(ab + bo + 4, g_lo, g_hi);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * NT);
+            if (q < q_hi) {
+                const uint32_t low = m2 == 0 ? b0[u] : (m2 == 1 ? __builtin_amdgcn_alignbyte(b1[u], b0[u], 1)
+                                                     : (m2 == 2 ? __builtin_amdgcn_alignbyte(b1[u], b0[u], 2)
+                                                                : __builtin_amdgcn_alignbyte(b1[u], b0[u], 3)));
+                const uint32_t diff = a[u] ^ low;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t at = 4u * q + k;  // byte offset from ab of byte k
+                    if (at >= P + mis && at < len + mis && ((diff >> (8u * k)) & 255u)) bad = true;
+                }
+            }
+        }
+    }
+    if (bad) sh.period_bad = 1;
+    __syncthreads();
+    const bool ok = sh.period_bad == 0;
+    __syncthreads();
+    return ok ? P : 0u;
+}
+
+// Writes the output of a block with whole-block period P from the suffix order of T2 = its last
+// 2 P symbols + delimiter: rank[x] (x = 0 .. 2 P) is the row of T2's suffix x among T2's suffixes.
+// sa2 / rowstart: scratch of 2 P + 2 words each.  Returns false if the rows do not add up (then
+// rank[] was not a permutation: an inconsistent sort).
+template <int NT>
+__device__ __noinline__ bool expand_periodic_block(const uint8_t* __restrict__ text, uint32_t len, uint32_t P,
+                                                    uint32_t delim, uint8_t* __restrict__ out,
+                                                    const uint32_t* __restrict__ rank, uint32_t* __restrict__ sa2,
+                                                    uint32_t* __restrict__ rowstart, FwdShared<NT>& sh) {
+    constexpr int W = NT / kWave;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t n2 = 2u * P + 1u, base = len - 2u * P;  // T2's suffix x is the block's suffix base + x
+    for (uint32_t x = tid; x < n2; x += NT) {
+        const uint32_t r = rank[x];
+        if (r < n2) sa2[r] = x;
+    }
+    __syncthreads();
+    // rows per element of T2's order: a first-period suffix stands for its whole chain
+    auto weight = [&](uint32_t x) { return x < P ? (base + x) / P + 1u : 1u; };
+    Chunking ck;
+    ck.init(n2, W);
+    const uint32_t lo = (uint32_t)w * ck.chunk, hi = min(lo + ck.chunk, n2);
+    {
+        uint32_t sum = 0;
+        for (uint32_t r = lo + lane; r < hi; r += kWave) sum += weight(sa2[r]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) sh.cntA[w] = sum;
+    }
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        if (i < w) run += sh.cntA[i];
+        total += sh.cntA[i];
+    }
+    for (uint32_t r0 = lo; r0 < hi; r0 += kWave) {
+        const uint32_t r = r0 + lane;
+        const uint32_t wt = r < hi ? weight(sa2[r]) : 0u;
+        const uint32_t incl = wave_inclusive_scan(wt);
+        if (r < hi) rowstart[r] = run + incl - wt;
+        run += __shfl(incl, kWave - 1);
+    }
+    __syncthreads();
+    if (total != len + 1u) return false;  // workgroup-uniform
+    // the chains run in ascending position when the delimiter is the larger symbol where they part
+    const bool asc = delim > (uint32_t)text[len - P];
+    if ((len + 1u) / n2 >= 32u) {
+        // long runs (short period): a wave per run, 4 bytes per lane and step
+        for (uint32_t r = (uint32_t)w; r < n2; r += W) {
+            const uint32_t x = sa2[r], j = base + x, row0 = rowstart[r], c = weight(x);
+            const uint32_t b = j ? (uint32_t)text[j - 1u] : delim;
+            uint8_t* o = out + row0;
+            const uint32_t head = min(c, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(o) & 3u)) & 3u));
+            const uint32_t nd = (c - head) / 4u;
+            if ((uint32_t)lane < head) o[lane] = (uint8_t)b;
+            uint32_t* od = reinterpret_cast<uint32_t*>(o + head);
+            for (uint32_t k = lane; k < nd; k += kWave) od[k] = b * 0x01010101u;
+            const uint32_t done = head + 4u * nd;
+            if (done + (uint32_t)lane < c) o[done + lane] = (uint8_t)b;
+        }
+    } else {
+        for (uint32_t r = tid; r < n2; r += NT) {
+            const uint32_t x = sa2[r], j = base + x, row0 = rowstart[r], c = weight(x);
+            const uint8_t b = j ? text[j - 1u] : (uint8_t)delim;
+            for (uint32_t k = 0; k < c; ++k) out[row0 + k] = b;
+        }
+    }
+    __syncthreads();
+    // the suffix at position 0 is preceded by the delimiter: it is the far end of the chain of the
+    // first-period suffix at the same position modulo P
+    if (tid == 0) {
+        const uint32_t x0 = (P - base % P) % P;  // (base + x0) % P == 0, x0 < P
+        const uint32_t r = rank[x0], c = weight(x0);
+        out[asc ? rowstart[r] : rowstart[r] + c - 1u] = (uint8_t)delim;
+    }
+    __syncthreads();
+    return true;
+}
+
 // HEAVY = false leaves out the machinery for blocks whose suffixes stay tied in long groups
 // (periodic runs, keys that dominate a bucket: cold code that costs the common case registers):
 // such a block is put off -- its index appended to a.deferred, nothing of it kept -- and done
 // from the start by a second launch of the HEAVY = true instantiation.
 template <int NT, bool HEAVY>
-__device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
+__device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s_block, uint32_t len_block, uint32_t delim,
                                               uint8_t* __restrict__ out, uint64_t* bufA, uint64_t* bufB,
                                               uint32_t* rank, FwdShared<NT>& sh, const FwdArgs& a, uint32_t b) {
     auto put_off = [&]() {
@@ -1944,13 +2132,29 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     constexpr int W = NT / kWave;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t* queue = a.queue;
-    const uint32_t n = len + 1;
-    if (n == 1) {  // empty block: just the delimiter (reference tests/test_small.cpp:83)
+    if (len_block == 0) {  // empty block: just the delimiter (reference tests/test_small.cpp:83)
         if (tid == 0) out[0] = (uint8_t)delim;
         return;
     }
     PhaseClock pc;
     pc.start(queue);
+    // A block that is periodic as a whole: only its last two periods are sorted (T2, see
+    // expand_periodic_block); everything below then works on that stretch, writes every rank, and the
+    // block's output is expanded from the result at the end.
+    const uint8_t* __restrict__ s = s_block;
+    uint32_t len = len_block;
+    uint32_t block_period = 0;
+    if (HEAVY && len_block >= kPeriodicMinBlock) {
+        block_period = detect_block_period<NT>(s_block, len_block, a.in, a.in + a.total_len, sh);
+        pc.lap(19);
+    }
+restart:
+    if (HEAVY && block_period) {
+        s = s_block + (len_block - 2u * block_period);
+        len = 2u * block_period;
+    }
+    const bool periodic = HEAVY && block_period != 0u;
+    const uint32_t n = len + 1;
     // ---- 0. census and codes ------------------------------------------------
     if (tid < 256) sh.sym[tid] = 0;
     __syncthreads();
@@ -1973,6 +2177,15 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         for (uint32_t i = head + 16u * nvec + tid; i < len; i += NT) sh.sym[s[i]] = 1;
     }
     __syncthreads();
+    if (HEAVY && periodic && sh.sym[delim]) {
+        // the delimiter occurs in the text (a caller's choice the file format never makes): the chain
+        // argument needs it to differ from every symbol, so the block is sorted as a whole
+        __syncthreads();
+        block_period = 0;
+        s = s_block;
+        len = len_block;
+        goto restart;
+    }
     const uint32_t present = tid < 256 ? sh.sym[tid] : 0;
     uint32_t sigma;  // distinct byte values in the text (the appended delimiter is not one of them)
     const uint32_t below = block_exclusive_scan<NT>(present, sh.wsum, sigma);
@@ -2101,7 +2314,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
             uint64_t bsub;
             lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh, up, bsub);
             pc.lap(12);
-            if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, sh, m, G);
+            if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic, sh, m, G);
             else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);
         }
@@ -2128,7 +2341,8 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
     io.delim = delim;
     bool full = false;
     __syncthreads();
-    if (!fused || m > n / 16u) rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, false, sh, m, G, full);
+    if (!fused || m > n / 16u) rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, periodic, sh, m, G, full);
+    else if (periodic) full = true;  // the fused rerank has written every rank
     pc.lap(3);
 
     // Tails with equal round-0 keys are not told apart by their ranks yet although their first m0
@@ -2193,7 +2407,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         }
         if (HEAVY && suspect) {
             const uint32_t left = G <= kTableGroups
-                                      ? resolve_periodic_groups<NT>(alt, cur, m, G, h, rank, io, ibits, gshift, sh)
+                                      ? resolve_periodic_groups<NT>(alt, cur, m, G, h, rank, io, ibits, gshift, periodic, sh)
                                       : resolve_short_periodic_groups<NT>(alt, cur, m, h, rank, io, ibits, gshift, period_hint, pc, sh);
             pc.lap(15);
             if (left != m) {
@@ -2304,6 +2518,13 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s, uin
         h = (h >= 0x40000000u) ? 0x80000000u : h * 2u;
     }
     __syncthreads();
+    if (HEAVY && periodic) {
+        // rank[] now holds the row of every suffix of T2; the key buffers are free
+        if (!expand_periodic_block<NT>(s_block, len_block, block_period, delim, out, rank, reinterpret_cast<uint32_t*>(bufA),
+                                       reinterpret_cast<uint32_t*>(bufB), sh) && tid == 0)
+            atomicOr(&queue[1], kErrBounds);
+        pc.lap(20);
+    }
     pc.count(8, 1);
 }
 

@@ -298,6 +298,54 @@ def test_periodic_runs(orc):
             assert api.inverse_batch(got, bs, delim) == data
 
 
+def test_whole_block_periods(orc):
+    """Blocks whose text is periodic throughout are sorted through their last two periods only:
+    periods from 1 to a third of the block, lengths that are no multiple of the period, delimiters
+    below, between and above the text symbols, the period broken at the first or last byte (then the
+    block is sorted as a whole), a prefix with a shorter period than the block, a delimiter that
+    occurs in the text, and batches of such blocks."""
+    rng = np.random.default_rng(4242)
+    cases = []
+
+    def unit(p, lo=1, hi=250):
+        while True:
+            u = rng.integers(lo, hi, size=p, dtype=np.uint8)
+            # the unit must not itself be periodic with a shorter period (then that one is found)
+            if all(not np.array_equal(u, np.roll(u, k)) for k in range(1, p) if p % k == 0):
+                return u
+
+    for p, length in [(1, 40000), (2, 33001), (3, 65537), (7, 262144), (7, 32768), (64, 131072), (100, 50001),
+                      (255, 40000), (256, 40000), (257, 99999), (1000, 70000), (5000, 45000), (11000, 33000),
+                      (10922, 32768), (10923, 32768), (152089 // 4, 300000)]:
+        u = unit(p)
+        data = np.tile(u, length // p + 2)[3:3 + length]
+        for delim in (0, 255, int(u.min()) + 1 if int(u.min()) + 1 not in set(u.tolist()) else 251):
+            if delim not in set(u.tolist()):
+                cases.append((data, length, delim))
+    u = unit(7)
+    base = np.tile(u, 6000)[:40000]
+    broken_first, broken_last, broken_mid = base.copy(), base.copy(), base.copy()
+    broken_first[0] ^= 1
+    broken_last[-1] ^= 1
+    broken_mid[23456] ^= 1
+    cases += [(broken_first, 40000, 0), (broken_last, 40000, 255), (broken_mid, 40000, 0)]
+    # the first 16 bytes repeat after 7 although the block's period is 3000
+    long_unit = np.concatenate([np.tile(u, 5)[:30], unit(2970)])
+    cases.append((np.tile(long_unit, 20)[:50000], 50000, 0))
+    # delimiter inside the text of a periodic block (API misuse): suffix order ties on the delimiter
+    cases.append((np.tile(u, 6000)[:40000], 40000, int(u[2])))
+    # batches: every block periodic (period 7 does not divide the block size, so the phase changes), ragged tail
+    cases.append((np.tile(u, 40000)[:5 * 40000 + 12345], 40000, 0))
+    cases.append((np.tile(unit(300), 3000)[:300 * 32768 // 4 + 99], 32768, 255))
+    for data, bs, delim in cases:
+        raw = data.tobytes()
+        want = b"".join(orc.forward(raw[i:i + bs], delim) for i in range(0, len(raw), bs))
+        got = api.forward_batch(raw, bs, delim)
+        assert got == want, (len(raw), bs, delim)
+        if raw.count(bytes([delim])) == 0:
+            assert api.inverse_batch(got, bs, delim) == raw
+
+
 def test_blocks_above_two_mib(orc, forward_path):
     """Blocks too long for the one-workgroup kernels: device-wide forward path, 64-bit inverse
     table words, coarser segments.  Against the oracle at 3 and 5 MiB, by round trip at 48 MiB."""
