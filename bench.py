@@ -196,7 +196,7 @@ def main() -> None:
         lens_ok = (bool((d_lens[:-1] == bs).all().item())
                    and int(d_lens[-1].item()) == nbytes - (nblocks - 1) * bs)
         status = d_ws_f[:8].cpu().numpy().view("uint32")  # [1] = forward kernel error flags
-        ph = d_ws_f[64:64 + 168].cpu().numpy().view("uint64").astype(float)
+        ph = d_ws_f[64:64 + 184].cpu().numpy().view("uint64").astype(float)
         names = ["census", "keys0_count", "partition0", "rerank0", "keys", "sort", "rerank", "rank_rebuild",
                  None, None, "bucket_rerank0_lds", "bucket_sort0_hbm", "bucket_sort0_lds",
                  "sort_lds", "rerank_lds", "periodic_runs", "periodic_vote", "periodic_breaks", "periodic_settle",
@@ -204,6 +204,7 @@ def main() -> None:
         tot = max(1.0, float(sum(v for k, v in zip(names, ph) if k)))
         phase_share = {k: round(float(v) / tot, 4) for k, v in zip(names, ph) if k}
         phase_share["later_rounds_per_block"] = round(float(ph[9]) / max(1.0, float(ph[8])), 3)
+        phase_share["short_stretch_given_up"] = [int(ph[21]), int(ph[22])]
         ok = torch.tensor([int(roundtrip_ok and lens_ok and int(status[1]) == 0)], device=dev)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

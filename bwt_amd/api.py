@@ -15,7 +15,8 @@ import sys
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libbwtgpu.so")
+# BWTGPU_LIB: another build of the same library (A/B experiments); the default is the in-tree one
+LIB_PATH = os.environ.get("BWTGPU_LIB") or os.path.join(_PKG, "libbwtgpu.so")
 
 OK = 0
 ERR_NO_DEVICE = -1

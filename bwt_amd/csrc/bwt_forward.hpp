@@ -85,7 +85,8 @@ constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition a
 // rounds' chunk sorts / chunk reranks in LDS, 15 periodic-run resolution (of which, for lists of
 // many short groups: 16 the vote, 17 the next-break table, 18 the settling sweep; the rest of 15 is
 // the compaction and the table variant), 19 the search for a whole-block period, 20 the expansion of
-// a periodic block's output from its last two periods.
+// a periodic block's output from its last periods, 21 / 22 blocks whose short stretch was given up for
+// two full periods (a periodic-run step was due / two heads were still tied).
 struct PhaseClock {
     unsigned long long t;
     unsigned long long* acc;
@@ -932,13 +933,15 @@ struct BlockIO {
 // (<= n/16, decided from the counting phase) the rank array is written for the survivors only
 // (`full_out` = false): the next round then ranks suffix i+h by binary search in cur
 // instead of reading rank[i+h].  `force_full` makes it write all ranks.
+// `bail_at`: when at least that many suffixes survive round 0 nothing is written at all (the caller
+// puts the block off).
 // Later rounds: cur holds the m survivors sorted by (group, rank of the suffix h further on);
 // ranks move up by the offset inside the old group; newly finished suffixes fetch their
 // preceding byte from the text.
 template <int NT, bool ROUND0>
 __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_t* __restrict__ nxt,
                                        uint32_t* __restrict__ rank, const BlockIO& io, uint32_t m, int ibits,
-                                       int kshift, int gshift, bool force_full, FwdShared<NT>& sh,
+                                       int kshift, int gshift, bool force_full, uint32_t bail_at, FwdShared<NT>& sh,
                                        uint32_t& m_next, uint32_t& g_next, bool& full_out) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
@@ -982,6 +985,13 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
         totG += g;
     }
     const bool full = !ROUND0 || force_full || totA > m / 16u;
+    if (ROUND0 && totA >= bail_at) {  // workgroup-uniform: the caller gives the block up if this many survive
+        m_next = totA;
+        g_next = totG;
+        full_out = false;
+        __syncthreads();
+        return;
+    }
     // phase C: ranks, output bytes of finished suffixes, compaction of the rest
     for_each_run_vector<ROUND0>(cur, lo, hi, m, kshift, gshift, [&](uint32_t base, const RunFlags& f) {
         const uint64_t H = __ballot(f.head), G = __ballot(f.ghead);
@@ -1949,110 +1959,164 @@ __device__ __noinline__ uint32_t resolve_short_periodic_groups(uint64_t* __restr
 // suffix array is T2's with every first-period suffix replaced by its chain, and the output is
 // T2's sorted order written out run by run: a chain's members all have the same preceding byte
 // (except the suffix at position 0, which has the delimiter).
-// period-7 text in 256 KiB blocks: 15 suffixes are sorted instead of 262 145; text tiled 6.9 times
-// in a 1 MiB block: 304 K instead of 1 M.
+// period-7 text in 256 KiB blocks: 15 suffixes are sorted instead of 262 145.
+//
+// Two full periods are more than the argument needs.  Let T be the block's last P + tail symbols
+// plus the delimiter (tail <= P; T2 is tail = P): its first P suffixes ("heads", one per position
+// modulo P, each with more than `tail` symbols of text) stand for their chains, the others for
+// themselves.  The chains stay contiguous as long as the P windows of `tail` symbols that start at
+// the heads are pairwise different -- a suffix that shares a head's whole text then still has to
+// be at the head's position modulo P.  That is checked while T is sorted: when the doubling
+// reaches a depth beyond `tail`, no group of still tied suffixes may hold two heads (and no
+// periodic-run step may have settled anything before); otherwise the block starts over with T2.
+// With a long period T2 has the drawback that EVERY suffix of its first period has a twin in the
+// second with which it stays tied for up to P symbols; the short T has only `tail` such pairs.
+// Text tiled 6.9 times in a 1 MiB block (period 152 089): 156 K suffixes of plain text are sorted
+// instead of 1 M tied seven-fold.
+constexpr uint32_t kShortTail = 4096;       // symbols of T beyond one period when the period is long ...
+constexpr uint32_t kShortTailMinPeriod = 8192;  // ... i.e. at least this (shorter periods: T2, which is small anyway)
 
-// The smallest whole-block period P with 3 P <= len, or 0.  The candidate is the first place where
-// the block's first 16 bytes occur again (any period is such a place, so the first one that holds
-// for the whole block is the smallest period; only that first place is tried).
+// The smallest whole-block period P with 3 P <= len, or 0.  A period P repeats EVERY window of the
+// text P places further on, so the candidates are the places where one chosen 16-byte window occurs
+// again, tried in ascending order: the first one that holds for the whole block is the smallest
+// period.  The window is the liveliest (most changes between neighbouring bytes) of sixteen near
+// the block's start -- a window inside a run of blanks would occur again at every step --, an
+// occurrence only counts if three more windows 1 KiB apart occur again with it, and a
+// candidate is dropped at its first mismatch, so a wrong one costs little; after kPeriodTries of
+// them the search gives up (the block is then sorted like any other).
+constexpr uint32_t kPeriodTries = 16;
+
 template <int NT>
 __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__ s, uint32_t len, const uint8_t* g_lo,
                                                       const uint8_t* g_hi, FwdShared<NT>& sh) {
-    const int tid = threadIdx.x;
-    if (len < 64u) return 0;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = lane_id();
+    if (len < 16384u) return 0;  // workgroup-uniform (the windows below reach 4 KiB + len / 3 into the block)
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3u);
     const uint8_t* ab = s - mis;  // dword-aligned; block position i is byte i + mis from here
-    if (tid == 0) {
-        sh.period_cand = 0xFFFFFFFFu;
-        sh.period_bad = 0;
+    if (wave_id() == 0) {  // the window: position 64 t, t < 16, with the most changes between neighbouring bytes
+        uint32_t score = 0;
+        if (lane < 16)
+            for (uint32_t k = 0; k < 15u; ++k) score += s[64u * lane + k] != s[64u * lane + k + 1u] ? 1u : 0u;
+        uint32_t best = (score << 8) | (uint32_t)(63 - lane);  // ties: the earliest
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor(best, o));
+        if (lane == 0) sh.period_cand = 64u * (63u - (best & 255u));
     }
     __syncthreads();
-    const uint32_t pat0 = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-    const uint32_t limit = len / 3u;  // candidates 1 .. limit
+    const uint32_t i0 = sh.period_cand;
+    __syncthreads();
+    const uint8_t* pat = s + i0;
+    const uint32_t pat0 = (uint32_t)pat[0] | ((uint32_t)pat[1] << 8) | ((uint32_t)pat[2] << 16) | ((uint32_t)pat[3] << 24);
+    const uint32_t limit = len / 3u;  // candidates 1 .. limit (window at i0 + candidate: i0 + len / 3 + 16 <= len)
     constexpr int U = 4;  // dword pairs whose loads are issued together
-    const uint32_t nq = (limit + mis) / 4u + 1u;
+    uint32_t from = 0;  // candidates up to here have been tried
 #pragma unroll 1
-    for (uint32_t q0 = (uint32_t)tid; q0 < nq; q0 += U * NT) {
-        uint32_t w0[U], w1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + (uint32_t)(u * NT);
-            w0[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
-            w1[u] = load_dword_guarded(ab + 4u * (uint64_t)q + 4u, g_lo, g_hi);
+    for (uint32_t attempt = 0; attempt < kPeriodTries; ++attempt) {
+        if (tid == 0) {
+            sh.period_cand = 0xFFFFFFFFu;
+            sh.period_bad = 0;
         }
+        __syncthreads();
+        // the first place after i0 + from where the window occurs again
+        const uint32_t q_first = (i0 + from + 1u + mis) / 4u, q_end = (i0 + limit + mis) / 4u + 1u;
+#pragma unroll 1
+        for (uint32_t q0 = q_first + (uint32_t)tid; q0 < q_end; q0 += U * NT) {
+            const uint32_t cand = *(volatile uint32_t*)&sh.period_cand;
+            if (cand != 0xFFFFFFFFu && cand + i0 + mis < 4u * (q0 - (uint32_t)tid)) break;  // every place from here on lies behind one already found
+            uint32_t w0[U], w1[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + (uint32_t)(u * NT);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * NT);
+                w0[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
+                w1[u] = load_dword_guarded(ab + 4u * (uint64_t)q + 4u, g_lo, g_hi);
+            }
 #pragma unroll
-            for (uint32_t o = 0; o < 4u; ++o) {
-                const uint32_t v = o == 0 ? w0[u] : __builtin_amdgcn_alignbyte(w1[u], w0[u], o);
-                const uint32_t at = 4u * q + o;  // byte offset from ab
-                if (v == pat0 && at > mis && at - mis <= limit) {
-                    const uint32_t i = at - mis;
-                    bool same = true;
-                    for (uint32_t k = 4; k < 16u; ++k) same = same && s[i + k] == s[k];  // i + 16 <= len / 3 + 16 <= len
-                    if (same) atomicMin(&sh.period_cand, i);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * NT);
+#pragma unroll
+                for (uint32_t o = 0; o < 4u; ++o) {
+                    const uint32_t v = o == 0 ? w0[u] : __builtin_amdgcn_alignbyte(w1[u], w0[u], o);
+                    const uint32_t at = 4u * q + o;  // byte offset from ab
+                    if (v == pat0 && at > i0 + from + mis && at - mis - i0 <= limit) {
+                        const uint32_t i = at - mis;  // block position of the occurrence
+                        // the window, and three more 1 KiB apart (a locally repetitive stretch -- a ruled
+                        // line in a text -- repeats the one window many times, but not all four)
+                        bool same = true;
+                        for (uint32_t wv = 0; wv < 4u && same; ++wv)
+                            for (uint32_t k = 0; k < 16u; ++k) same = same && s[i + 1024u * wv + k] == pat[1024u * wv + k];
+                        if (same) atomicMin(&sh.period_cand, i - i0);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    const uint32_t P = sh.period_cand;
-    if (P == 0xFFFFFFFFu) return 0;  // workgroup-uniform
-    // does the text repeat at distance P everywhere?  aligned dwords of the upper copy against the
-    // bytes P below them (two aligned dwords and a funnel shift: the misalignment is the same everywhere)
-    const uint32_t m2 = (0u - P) & 3u;
-    const uint32_t q_lo = (P + mis) / 4u, q_hi = (len + mis + 3u) / 4u;  // dwords that hold positions P .. len-1
-    bool bad = false;
+        __syncthreads();
+        const uint32_t P = sh.period_cand;
+        if (P == 0xFFFFFFFFu) return 0;  // workgroup-uniform
+        // does the text repeat at distance P everywhere?  aligned dwords of the upper copy against the
+        // bytes P below them (two aligned dwords and a funnel shift: the misalignment is the same everywhere)
+        const uint32_t m2 = (0u - P) & 3u;
+        const uint32_t q_lo = (P + mis) / 4u, q_hi = (len + mis + 3u) / 4u;  // dwords that hold positions P .. len-1
+        bool bad = false;
 #pragma unroll 1
-    for (uint32_t q0 = q_lo + (uint32_t)tid; q0 < q_hi; q0 += U * NT) {
-        uint32_t a[U], b0[U], b1[U];
+        for (uint32_t q0 = q_lo + (uint32_t)tid; q0 < q_hi; q0 += U * NT) {
+            if (*(volatile uint32_t*)&sh.period_bad) break;  // somebody has found a mismatch
+            uint32_t a[U], b0[U], b1[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + (uint32_t)(u * NT);
-            const int64_t bo = (int64_t)4 * q - (int64_t)P - (int64_t)m2;  // aligned byte offset of the lower dword pair
-            a[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
-            b0[u] = load_dword_guarded(ab + bo, g_lo, g_hi);
-            b1[u] = load_dword_guarded(ab + bo + 4, g_lo, g_hi);
-        }
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * NT);
+                const int64_t bo = (int64_t)4 * q - (int64_t)P - (int64_t)m2;  // aligned byte offset of the lower dword pair
+                a[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
+                b0[u] = load_dword_guarded(ab + bo, g_lo, g_hi);
+                b1[u] = load_dword_guarded(ab + bo + 4, g_lo, g_hi);
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + (uint32_t)(u * NT);
-            if (q < q_hi) {
-                const uint32_t low = m2 == 0 ? b0[u] : (m2 == 1 ? __builtin_amdgcn_alignbyte(b1[u], b0[u], 1)
-                                                     : (m2 == 2 ? __builtin_amdgcn_alignbyte(b1[u], b0[u], 2)
-                                                                : __builtin_amdgcn_alignbyte(b1[u], b0[u], 3)));
-                const uint32_t diff = a[u] ^ low;
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * NT);
+                if (q < q_hi) {
+                    const uint32_t low = m2 == 0 ? b0[u] : (m2 == 1 ? __builtin_amdgcn_alignbyte(b1[u], b0[u], 1)
+                                                         : (m2 == 2 ? __builtin_amdgcn_alignbyte(b1[u], b0[u], 2)
+                                                                    : __builtin_amdgcn_alignbyte(b1[u], b0[u], 3)));
+                    const uint32_t diff = a[u] ^ low;
 #pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t at = 4u * q + k;  // byte offset from ab of byte k
-                    if (at >= P + mis && at < len + mis && ((diff >> (8u * k)) & 255u)) bad = true;
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t at = 4u * q + k;  // byte offset from ab of byte k
+                        if (at >= P + mis && at < len + mis && ((diff >> (8u * k)) & 255u)) bad = true;
+                    }
                 }
             }
+            if (bad) *(volatile uint32_t*)&sh.period_bad = 1;
         }
+        __syncthreads();
+        const bool ok = sh.period_bad == 0;
+        __syncthreads();
+        if (ok) return P;
+        from = P;
     }
-    if (bad) sh.period_bad = 1;
-    __syncthreads();
-    const bool ok = sh.period_bad == 0;
-    __syncthreads();
-    return ok ? P : 0u;
+    return 0u;
 }
 
-// Writes the output of a block with whole-block period P from the suffix order of T2 = its last
-// 2 P symbols + delimiter: rank[x] (x = 0 .. 2 P) is the row of T2's suffix x among T2's suffixes.
-// sa2 / rowstart: scratch of 2 P + 2 words each.  Returns false if the rows do not add up (then
-// rank[] was not a permutation: an inconsistent sort).
+// Writes the output of a block with whole-block period P from the suffix order of T = its last
+// P + tail symbols + delimiter: rank[x] (x = 0 .. P + tail) is the row of T's suffix x among T's
+// suffixes.  sa2 / rowstart: scratch of P + tail + 2 words each.  Returns false if the rows do not
+// add up (then rank[] was not a permutation: an inconsistent sort).
 template <int NT>
 __device__ __noinline__ bool expand_periodic_block(const uint8_t* __restrict__ text, uint32_t len, uint32_t P,
-                                                    uint32_t delim, uint8_t* __restrict__ out,
+                                                    uint32_t tail, uint32_t delim, uint8_t* __restrict__ out,
                                                     const uint32_t* __restrict__ rank, uint32_t* __restrict__ sa2,
                                                     uint32_t* __restrict__ rowstart, FwdShared<NT>& sh) {
     constexpr int W = NT / kWave;
+    constexpr int U = 4;  // independent elements per thread whose loads are issued together
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const uint32_t n2 = 2u * P + 1u, base = len - 2u * P;  // T2's suffix x is the block's suffix base + x
-    for (uint32_t x = tid; x < n2; x += NT) {
-        const uint32_t r = rank[x];
-        if (r < n2) sa2[r] = x;
+    const uint32_t n2 = P + tail + 1u, base = len - P - tail;  // T's suffix x is the block's suffix base + x
+    for (uint32_t x0 = tid; x0 < n2; x0 += U * NT) {
+        uint32_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = rank[min(x0 + (uint32_t)(u * NT), n2 - 1u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t x = x0 + (uint32_t)(u * NT);
+            if (x < n2 && r[u] < n2) sa2[r[u]] = x;
+        }
     }
     __syncthreads();
     // rows per element of T2's order: a first-period suffix stands for its whole chain
@@ -2100,10 +2164,27 @@ __device__ __noinline__ bool expand_periodic_block(const uint8_t* __restrict__ t
             if (done + (uint32_t)lane < c) o[done + lane] = (uint8_t)b;
         }
     } else {
-        for (uint32_t r = tid; r < n2; r += NT) {
-            const uint32_t x = sa2[r], j = base + x, row0 = rowstart[r], c = weight(x);
-            const uint8_t b = j ? text[j - 1u] : (uint8_t)delim;
-            for (uint32_t k = 0; k < c; ++k) out[row0 + k] = b;
+        for (uint32_t r0 = tid; r0 < n2; r0 += U * NT) {
+            uint32_t x[U], row0[U];
+            uint8_t b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = min(r0 + (uint32_t)(u * NT), n2 - 1u);
+                x[u] = sa2[r];
+                row0[u] = rowstart[r];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = base + x[u];
+                b[u] = j ? text[j - 1u] : (uint8_t)delim;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r0 + (uint32_t)(u * NT) < n2) {
+                    const uint32_t c = weight(x[u]);
+                    for (uint32_t k = 0; k < c; ++k) out[row0[u] + k] = b[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -2116,6 +2197,39 @@ __device__ __noinline__ bool expand_periodic_block(const uint8_t* __restrict__ t
     }
     __syncthreads();
     return true;
+}
+
+// Whether some group of the survivor list (elements group << gshift | index, sorted by group) holds
+// two heads, i.e. two suffixes with index below P.  Every head looks back through its group for
+// another one; a group too long to look through (more than kHeadLookBack elements before the
+// head) counts as a failure, which only costs the caller the short cut.
+constexpr uint32_t kHeadLookBack = 32;
+
+template <int NT>
+__device__ __noinline__ bool two_heads_in_a_group(const uint64_t* __restrict__ list, uint32_t m, uint32_t P, int ibits,
+                                                   int gshift, FwdShared<NT>& sh) {
+    const uint64_t imask = (1ull << ibits) - 1ull;
+    if (threadIdx.x == 0) sh.period_bad = 0;
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t k = threadIdx.x; k < m; k += NT) {
+        const uint64_t e = list[k];
+        if ((uint32_t)(e & imask) >= P) continue;
+        const uint64_t g = e >> gshift;
+        for (uint32_t t = 1; t <= k; ++t) {
+            const uint64_t e2 = list[k - t];
+            if ((e2 >> gshift) != g) break;
+            if ((uint32_t)(e2 & imask) < P || t == kHeadLookBack) {
+                bad = true;
+                break;
+            }
+        }
+    }
+    if (bad) sh.period_bad = 1;
+    __syncthreads();
+    const bool r = sh.period_bad != 0u;
+    __syncthreads();
+    return r;
 }
 
 // HEAVY = false leaves out the machinery for blocks whose suffixes stay tied in long groups
@@ -2143,17 +2257,20 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s_bloc
     // block's output is expanded from the result at the end.
     const uint8_t* __restrict__ s = s_block;
     uint32_t len = len_block;
-    uint32_t block_period = 0;
+    uint32_t block_period = 0, period_tail = 0;
     if (HEAVY && len_block >= kPeriodicMinBlock) {
         block_period = detect_block_period<NT>(s_block, len_block, a.in, a.in + a.total_len, sh);
+        period_tail = block_period >= kShortTailMinPeriod ? kShortTail : block_period;
         pc.lap(19);
     }
 restart:
     if (HEAVY && block_period) {
-        s = s_block + (len_block - 2u * block_period);
-        len = 2u * block_period;
+        s = s_block + (len_block - block_period - period_tail);
+        len = block_period + period_tail;
     }
     const bool periodic = HEAVY && block_period != 0u;
+    // the short T is only good if its heads prove to be told apart within `tail` symbols (checked below)
+    bool heads_unchecked = periodic && period_tail < block_period;
     const uint32_t n = len + 1;
     // ---- 0. census and codes ------------------------------------------------
     if (tid < 256) sh.sym[tid] = 0;
@@ -2181,7 +2298,7 @@ restart:
         // the delimiter occurs in the text (a caller's choice the file format never makes): the chain
         // argument needs it to differ from every symbol, so the block is sorted as a whole
         __syncthreads();
-        block_period = 0;
+        block_period = period_tail = 0;
         s = s_block;
         len = len_block;
         goto restart;
@@ -2341,8 +2458,18 @@ restart:
     io.delim = delim;
     bool full = false;
     __syncthreads();
-    if (!fused || m > n / 16u) rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, periodic, sh, m, G, full);
-    else if (periodic) full = true;  // the fused rerank has written every rank
+    if (!fused || m > n / 16u) {
+        // (nearly) every suffix with a twin after round 0 is repeated text: the common-case kernel
+        // learns that from the count and leaves the block to the other one before the costly sweep
+        const uint32_t bail_at = !HEAVY && n >= kPeriodicMinBlock ? n - 64u : 0xFFFFFFFFu;
+        rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, periodic, bail_at, sh, m, G, full);
+        if (!HEAVY && m >= bail_at) {  // workgroup-uniform
+            put_off();
+            return;
+        }
+    } else if (periodic) {
+        full = true;  // the fused rerank has written every rank
+    }
     pc.lap(3);
 
     // Tails with equal round-0 keys are not told apart by their ranks yet although their first m0
@@ -2404,6 +2531,17 @@ restart:
         if (!HEAVY && suspect) {  // workgroup-uniform
             put_off();
             return;
+        }
+        if (HEAVY && heads_unchecked && (suspect || 2u * h > period_tail)) {
+            // the doubling is about to look beyond the `tail` symbols every head is sure to have (or a
+            // periodic-run step is about to settle groups at any depth): no group may hold two heads
+            const bool tied_heads = !suspect && two_heads_in_a_group<NT>(alt, m, block_period, ibits, gshift, sh);
+            if (suspect || tied_heads) {  // workgroup-uniform
+                pc.count(suspect ? 21 : 22, 1);
+                period_tail = block_period;  // start over with two full periods
+                goto restart;
+            }
+            heads_unchecked = false;
         }
         if (HEAVY && suspect) {
             const uint32_t left = G <= kTableGroups
@@ -2497,7 +2635,7 @@ restart:
             pc.lap(5);
             other = (sorted == alt) ? cur : alt;
             bool unused;
-            rerank<NT, false>(sorted, other, rank, io, m, ibits, ibits, gshift, true, sh, m2, G2, unused);
+            rerank<NT, false>(sorted, other, rank, io, m, ibits, ibits, gshift, true, 0xFFFFFFFFu, sh, m2, G2, unused);
             pc.lap(6);
         }
         pc.count(9, 1);
@@ -2505,7 +2643,7 @@ restart:
             if (m2 == 0) break;
             // survivors remain after the searched round: build the complete rank array from the
             // round-0 order and redo this round with it (rare: long repeats in otherwise easy data)
-            rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, true, sh, m, G, full);
+            rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, true, 0xFFFFFFFFu, sh, m, G, full);
             cur = sorted0;
             alt = spare;
             pc.lap(7);
@@ -2519,8 +2657,8 @@ restart:
     }
     __syncthreads();
     if (HEAVY && periodic) {
-        // rank[] now holds the row of every suffix of T2; the key buffers are free
-        if (!expand_periodic_block<NT>(s_block, len_block, block_period, delim, out, rank, reinterpret_cast<uint32_t*>(bufA),
+        // rank[] now holds the row of every suffix of T; the key buffers are free
+        if (!expand_periodic_block<NT>(s_block, len_block, block_period, period_tail, delim, out, rank, reinterpret_cast<uint32_t*>(bufA),
                                        reinterpret_cast<uint32_t*>(bufB), sh) && tid == 0)
             atomicOr(&queue[1], kErrBounds);
         pc.lap(20);

@@ -613,7 +613,16 @@ int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_
     } else {
         // the common case first; the blocks it puts off (periodic runs, dominant keys) in a second
         // launch of the full kernel, which finds an empty list otherwise
+        static const bool heavy_only = std::getenv("BWTGPU_PHASES") && !strcmp(std::getenv("BWTGPU_PHASES"), "heavy_only");
+        if (heavy_only) {  // debugging aid: every block through the full kernel
+            hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, true>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 0);
+            HIP_TRY(hipGetLastError());
+            return BWTGPU_OK;
+        }
         hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 0);
+        // debugging aid: BWTGPU_PHASES=second makes the phase clocks in the header cover the second launch only
+        static const bool second_only = std::getenv("BWTGPU_PHASES") && !strcmp(std::getenv("BWTGPU_PHASES"), "second");
+        if (second_only) HIP_TRY(hipMemsetAsync(ws + 64, 0, kHeaderBytes - 64, s));
         hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, true>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 1);
     }
     HIP_TRY(hipGetLastError());
@@ -1058,8 +1067,8 @@ int bwtgpu_synth_device(int device, int kind, uint64_t seed, uint64_t offset, ui
                         const uint8_t* d_text, size_t text_len, void* stream) {
     int rc = check_device(device);
     if (rc) return rc;
-    if (kind < 0 || kind > 5) return fail(BWTGPU_ERR_INVALID, "unknown synthetic kind %d", kind);
-    if (kind == 5 && (!d_text || text_len == 0)) return fail(BWTGPU_ERR_INVALID, "kind 5 needs a text sample");
+    if (kind < 0 || kind > 6) return fail(BWTGPU_ERR_INVALID, "unknown synthetic kind %d", kind);
+    if (kind >= 5 && (!d_text || text_len == 0)) return fail(BWTGPU_ERR_INVALID, "kinds 5 and 6 need a text sample");
     if (len == 0) return BWTGPU_OK;
     if (!d_out) return fail(BWTGPU_ERR_INVALID, "null device pointer");
     HIP_TRY(hipSetDevice(device));

@@ -19,6 +19,7 @@ Kinds
 ``period7``    ``"abcdefg"[i % 7]``.
 ``period1``    ``"a"``.
 ``period64``   a 64-byte ``random255`` unit (stream positions 0..63) repeated.
+``text``       a caller-supplied sample (alice29.txt) tiled: byte ``i`` is ``text[i % len(text)]``.
 ``mixed``      1 MiB segments cycling random255 / acgt / period7 / text, the text
                segments tiling a caller-supplied sample (alice29.txt).
 """
@@ -27,7 +28,7 @@ from __future__ import annotations
 import numpy as np
 
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
-KINDS = {"random255": 0, "acgt": 1, "period7": 2, "period1": 3, "period64": 4, "mixed": 5}
+KINDS = {"random255": 0, "acgt": 1, "period7": 2, "period1": 3, "period64": 4, "mixed": 5, "text": 6}
 SEGMENT = 1 << 20
 
 
@@ -89,6 +90,12 @@ def generate(kind: str, seed: int, offset: int, length: int, text: bytes | None 
         unit = _random255(seed, 0, 64)
         i = np.arange(offset, offset + length, dtype=np.uint64) % np.uint64(64)
         return unit[i.astype(np.int64)]
+    if kind == "text":
+        if not text:
+            raise ValueError("kind 'text' needs a text sample")
+        t = np.frombuffer(text, dtype=np.uint8)
+        i = np.arange(offset, offset + length, dtype=np.uint64) % np.uint64(t.size)
+        return t[i.astype(np.int64)]
     if kind == "mixed":
         if not text:
             raise ValueError("kind 'mixed' needs a text sample")

@@ -166,7 +166,7 @@ int bwtgpu_lowest_clear_bit(const uint32_t presence[8]);
 
 /* ---- synthetic inputs (benchmark / test plumbing) ----------------------------
  * Writes bytes [offset, offset+len) of stream (kind, seed) to d_out; kinds:
- * 0 random255, 1 acgt, 2 period7, 3 period1, 4 period64, 5 mixed (needs d_text). */
+ * 0 random255, 1 acgt, 2 period7, 3 period1, 4 period64, 5 mixed, 6 text tiled (5 and 6 need d_text). */
 int bwtgpu_synth_device(int device, int kind, uint64_t seed, uint64_t offset, uint8_t* d_out,
                         size_t len, const uint8_t* d_text, size_t text_len, void* stream);
 
