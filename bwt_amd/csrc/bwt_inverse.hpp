@@ -97,7 +97,9 @@ struct InvArgs {
     uint32_t* drow;       // per block: delimiter row or kNoRow
     uint32_t* mode;       // per block: kModeMulti / kModeSingle / kModeNone
     uint2* seg;           // nblocks * seg_cap: x = bytes the segment produces, y = id of the splitter it runs into
-    uint32_t* seg_pos;    // nblocks * seg_cap: bytes between the segment's first byte and the text end
+    uint2* seg_rec;       // nblocks * seg_cap: the segments in the order the chain visits them (= the text back to front):
+                          // x = segment id, y = bytes between the segment's first byte and the text end
+    uint2* chain;         // per block: x = segments on the chain, y = bytes they produce
     uint32_t split_shift; // log2 of the rows between regular splitters
     uint32_t slot;        // bytes of staging per segment (power of two); longer segments chain pool chunks of the same size
     uint8_t* stage;       // nblocks * seg_cap * slot: the first `slot` bytes of every segment, in walk order
@@ -545,7 +547,6 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
     if (j > nreg) return;
     const uint32_t drow = a.drow[b];
     const uint64_t sb = (uint64_t)b * a.seg_cap;
-    if (a.split_shift != kMinSplitShift) a.seg_pos[sb + j] = kNoPos;  // the LDS stitch writes every position itself
     const int last = b + 1u == a.nblocks ? 1 : 0;
     const uint32_t start = j < nreg ? mul_mod(j, a.split_inv[last], n) : drow;
     if (j < nreg && start == drow) {
@@ -605,19 +606,60 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(
 }
 
 // Orders the segments of every split block: start at the delimiter row's segment, follow the
-// next-splitter links until the chain returns to it.  seg_pos = bytes before the segment,
-// counted from the END of the text (the walk produces the text back to front).
+// next-splitter links until the chain returns to it.  The result is seg_rec: the segments in chain
+// order, each with the bytes before it counted from the END of the text (the walk produces the
+// text back to front).
 // One workgroup per block.  Following thousands of links one after the other would take
 // milliseconds, so every kSuperStride-th segment (and the delimiter's) is a "super" node:
 // each thread follows the links from its super node to the next one, summing the lengths
 // (short independent chains), one thread then orders the few hundred super nodes, and each
-// thread walks its chain again to hand out the positions.
+// thread walks its chain again to hand out the ordinals and positions.
 constexpr uint32_t kSuperStride = 32;
 constexpr uint32_t kMaxSupers = kMaxSegments / kSuperStride + 2u;
+constexpr uint32_t kSuperNone = 0x1FFFu;  // "no next super node" in the packed word below
+static_assert(kMaxSupers < kSuperNone && kMaxSegments < (1u << 18), "next super node in 13 bits, segment count above it");
+
+// What a super node's chain adds up to: bytes, segments, and the super node it ends at.
+struct SuperChain {
+    uint32_t bytes, segments, next;
+};
+// Follows the links from segment `id` to the next super node (bounded: a malformed block may link
+// segments in a cycle).  seg_at(id) -> {bytes, next id}; super_of(id) -> super index or kNoPos.
+template <typename SegAt, typename SuperOf>
+__device__ __forceinline__ SuperChain follow_to_super(uint32_t id, uint32_t nreg, SegAt seg_at, SuperOf super_of) {
+    SuperChain c{0u, 0u, kNoPos};
+    for (uint32_t it = 0; it <= nreg; ++it) {
+        const uint2 sg = seg_at(id);
+        c.bytes += sg.x;
+        ++c.segments;
+        c.next = super_of(sg.y);
+        if (c.next != kNoPos) break;
+        id = min(sg.y, nreg);
+    }
+    return c;
+}
+
+// One thread orders the super nodes: s_sum[u] (bytes of u's chain) becomes the ordinal of its first
+// segment on the block's chain, s_pos[u] the bytes before it; returns {segments, bytes} of the
+// whole chain.  s_nc[u] = segments << 13 | next super (kSuperNone: none).
+__device__ __forceinline__ uint2 order_supers(uint32_t last, uint32_t* s_sum, uint32_t* s_nc, uint32_t* s_pos) {
+    uint32_t cur = last, bytes = 0, segs = 0;
+    for (uint32_t it = 0; it <= last; ++it) {
+        const uint32_t nc = s_nc[cur];
+        s_pos[cur] = bytes;
+        bytes += s_sum[cur];
+        s_sum[cur] = segs;
+        segs += nc >> 13;
+        const uint32_t nx = nc & kSuperNone;
+        if (nx == last || nx == kSuperNone) break;  // back at the delimiter row: the text is complete
+        cur = nx;
+    }
+    return make_uint2(segs, bytes);
+}
 
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
-    __shared__ uint32_t s_sum[kMaxSupers], s_next[kMaxSupers], s_pos[kMaxSupers];
+    __shared__ uint32_t s_sum[kMaxSupers], s_nc[kMaxSupers], s_pos[kMaxSupers];
     const uint32_t b = blockIdx.x;
     if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
@@ -628,43 +670,31 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
         if (id >= nreg) return last;
         return (id % kSuperStride) == 0u ? id / kSuperStride : kNoPos;
     };
+    auto seg_at = [&](uint32_t id) { return a.seg[sb + id]; };
     for (uint32_t u = threadIdx.x; u <= last; u += NT) {
-        uint32_t id = u == last ? nreg : u * kSuperStride;
-        uint32_t sum = 0, nx = kNoPos;
-        for (uint32_t it = 0; it <= nreg; ++it) {  // bounded: a malformed block may link segments in a cycle
-            const uint2 sg = a.seg[sb + id];
-            sum += sg.x;
-            nx = super_of(sg.y);
-            if (nx != kNoPos) break;
-            id = sg.y;
-        }
-        s_sum[u] = sum;
-        s_next[u] = nx;
+        const SuperChain c = follow_to_super(u == last ? nreg : u * kSuperStride, nreg, seg_at, super_of);
+        s_sum[u] = c.bytes;
+        s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
         s_pos[u] = kNoPos;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t cur = last, total = 0;
-        for (uint32_t it = 0; it <= last; ++it) {
-            s_pos[cur] = total;
-            total += s_sum[cur];
-            const uint32_t nx = s_next[cur];
-            if (nx == last || nx == kNoPos) break;  // back at the delimiter row: the text is complete
-            cur = nx;
-        }
-        a.lens[b] = total < n ? total : n - 1;
+        const uint2 whole = order_supers(last, s_sum, s_nc, s_pos);
+        a.chain[b] = whole;
+        a.lens[b] = whole.y < n ? whole.y : n - 1;
     }
     __syncthreads();
     for (uint32_t u = threadIdx.x; u <= last; u += NT) {
         uint32_t pos = s_pos[u];
         if (pos == kNoPos) continue;  // a chain the delimiter's chain never reaches
-        uint32_t id = u == last ? nreg : u * kSuperStride;
+        uint32_t id = u == last ? nreg : u * kSuperStride, ord = s_sum[u];
         for (uint32_t it = 0; it <= nreg; ++it) {
             const uint2 sg = a.seg[sb + id];
-            a.seg_pos[sb + id] = pos;
+            if (ord < a.seg_cap) a.seg_rec[sb + ord] = make_uint2(id, pos);
+            ++ord;
             pos += sg.x;
             if (super_of(sg.y) != kNoPos) break;
-            id = sg.y;
+            id = min(sg.y, nreg);
         }
     }
 }
@@ -675,12 +705,11 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
 constexpr uint32_t kStitchLdsSegs = 16640;
 constexpr uint32_t kLdsSuperStride = 32;  // measured: 128 is slower (the longest of the chains sets the pace), 32 balances chains against the serial pass over super nodes
 constexpr uint32_t kStitchLdsSupers = kStitchLdsSegs / kLdsSuperStride + 2u;
-constexpr uint32_t kVisited = 0x80000000u;
 
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
     __shared__ uint2 s_seg[kStitchLdsSegs];
-    __shared__ uint32_t s_sum[kStitchLdsSupers], s_next[kStitchLdsSupers], s_pos[kStitchLdsSupers];
+    __shared__ uint32_t s_sum[kStitchLdsSupers], s_nc[kStitchLdsSupers], s_pos[kStitchLdsSupers];
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
         if (a.mode[b] != kModeMulti) continue;  // workgroup-uniform
         const uint32_t n = inv_block_len(a, b);
@@ -691,51 +720,34 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
             if (id >= nreg) return last;
             return (id % kLdsSuperStride) == 0u ? id / kLdsSuperStride : kNoPos;
         };
+        auto seg_at = [&](uint32_t id) { return s_seg[id]; };
         for (uint32_t i = threadIdx.x; i <= nreg; i += NT) s_seg[i] = a.seg[sb + i];
         __syncthreads();
         for (uint32_t u = threadIdx.x; u <= last; u += NT) {
-            uint32_t id = u == last ? nreg : u * kLdsSuperStride;
-            uint32_t sum = 0, nx = kNoPos;
-            for (uint32_t it = 0; it <= nreg; ++it) {
-                const uint2 sg = s_seg[id];
-                sum += sg.x;
-                nx = super_of(sg.y);
-                if (nx != kNoPos) break;
-                id = min(sg.y, nreg);
-            }
-            s_sum[u] = sum;
-            s_next[u] = nx;
+            const SuperChain c = follow_to_super(u == last ? nreg : u * kLdsSuperStride, nreg, seg_at, super_of);
+            s_sum[u] = c.bytes;
+            s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
             s_pos[u] = kNoPos;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t cur = last, total = 0;
-            for (uint32_t it = 0; it <= last; ++it) {
-                s_pos[cur] = total;
-                total += s_sum[cur];
-                const uint32_t nx = s_next[cur];
-                if (nx == last || nx == kNoPos) break;
-                cur = nx;
-            }
-            a.lens[b] = total < n ? total : n - 1;
+            const uint2 whole = order_supers(last, s_sum, s_nc, s_pos);
+            a.chain[b] = whole;
+            a.lens[b] = whole.y < n ? whole.y : n - 1;
         }
         __syncthreads();
         for (uint32_t u = threadIdx.x; u <= last; u += NT) {
             uint32_t pos = s_pos[u];
             if (pos == kNoPos) continue;
-            uint32_t id = u == last ? nreg : u * kLdsSuperStride;
+            uint32_t id = u == last ? nreg : u * kLdsSuperStride, ord = s_sum[u];
             for (uint32_t it = 0; it <= nreg; ++it) {
                 const uint2 sg = s_seg[id];
-                s_seg[id] = make_uint2(sg.x | kVisited, pos);  // every segment lies on one super node's chain only
+                if (ord < a.seg_cap) a.seg_rec[sb + ord] = make_uint2(id, pos);
+                ++ord;
                 pos += sg.x;
                 if (super_of(sg.y) != kNoPos) break;
                 id = min(sg.y, nreg);
             }
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i <= nreg; i += NT) {
-            const uint2 sg = s_seg[i];
-            a.seg_pos[sb + i] = (sg.x & kVisited) ? sg.y : kNoPos;
         }
         __syncthreads();
     }
@@ -743,16 +755,20 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
 
 // Moves every chained segment from its staging slot (and pool chunks) to its place: the bytes
 // were produced back to front, so byte t of the segment lands t + 1 bytes below its upper end.
+// Lane k takes the k-th segment ON THE CHAIN (seg_rec), not segment k: neighbouring lanes then
+// write neighbouring stretches of the text, which the L2 merges into whole lines (with lane =
+// segment id every lane wrote its 16 bytes or so to a place of its own, and the pass wrote 2.8
+// times its payload to HBM); what stays random is the read of the segment's staging line.
 __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
-    uint32_t b, j;
-    if (!segment_of_lane(a, b, j)) return;
+    uint32_t b, k;
+    if (!segment_of_lane(a, b, k)) return;
     const uint32_t n = inv_block_len(a, b);
-    const uint32_t nreg = regular_splitters(n, a.split_shift);
-    if (j > nreg) return;
     const uint64_t sb = (uint64_t)b * a.seg_cap;
-    const uint32_t pos = a.seg_pos[sb + j];
-    if (pos == kNoPos) return;  // a segment on a cycle the delimiter's chain never reaches
-    const uint32_t len = a.seg[sb + j].x;
+    const uint2 whole = a.chain[b];
+    if (k >= whole.x || k >= a.seg_cap) return;  // segments off the chain (a cycle the delimiter's chain never reaches) have no place
+    const uint2 rec = a.seg_rec[sb + k];
+    const uint32_t j = rec.x, pos = rec.y;
+    const uint32_t len = (k + 1u < whole.x ? a.seg_rec[sb + k + 1u].y : whole.y) - pos;
     if ((uint64_t)pos + len > (uint64_t)(n - 1)) return;  // never: the chain is at most n-1 bytes long
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
     const uint8_t* src = a.stage + (sb + j) * a.slot;

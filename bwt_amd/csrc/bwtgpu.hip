@@ -232,7 +232,7 @@ struct InvGeom {
     bool wide;   // blocks of more than kNarrowMaxRows rows: 64-bit table words
     uint32_t tile_rows, tiles_per_block;
     size_t dacc_off, thist_off;
-    size_t drow_off, mode_off, used_off, seg_off, segpos_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
+    size_t drow_off, mode_off, used_off, chain_off, seg_off, segrec_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
 
 // Multiplier of the splitter map row -> row * mul mod n of the inverse (bwt_inverse.hpp) and its
@@ -303,8 +303,9 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.drow_off = take(g.nblocks * 4);
     g.mode_off = take(g.nblocks * 4);
     g.used_off = take(g.nblocks * 4);
+    g.chain_off = take(g.nblocks * 8);
     g.seg_off = take(g.nblocks * g.seg_cap * 8);
-    g.segpos_off = take(g.nblocks * g.seg_cap * 4);
+    g.segrec_off = take(g.split ? g.nblocks * g.seg_cap * 8 : 0);
     g.segovf_off = take(g.nblocks * g.seg_cap * 4);
     g.next_off = take(g.nblocks * (size_t)g.chunk_cap * 4);
     g.stage_off = take(g.split ? g.nblocks * (size_t)g.seg_cap * g.slot : 0);
@@ -860,7 +861,8 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.drow = (uint32_t*)(ws + g.drow_off);
     a.mode = (uint32_t*)(ws + g.mode_off);
     a.seg = (uint2*)(ws + g.seg_off);
-    a.seg_pos = (uint32_t*)(ws + g.segpos_off);
+    a.seg_rec = (uint2*)(ws + g.segrec_off);
+    a.chain = (uint2*)(ws + g.chain_off);
     a.stage = ws + g.stage_off;
     a.seg_ovf = (uint32_t*)(ws + g.segovf_off);
     a.chunk_cap = g.chunk_cap;
