@@ -10,7 +10,13 @@ shard.  Rank 0 prints ONE JSON line.  `value` is input bytes of all ranks per se
 (forward + inverse), GB = 1e9 bytes.  `roofline` prices the dominant kernel (the forward
 suffix-sort kernel) at its algorithmic bytes (read N, write N + nblocks per launch) over
 its HIP-event duration; `cpu_baseline` times the reference CPU implementation on a bounded
-sample of the same workload on this host's cores.
+sample of the same workload on this host's cores.  Beside the headline the line carries
+  other_workloads   the other benchmark configurations (each with its own roofline entries, and the
+                    Canterbury alice29.txt case with the CPU reference timed on the whole file),
+  kernels           per-kernel time / algorithmic bytes / counter traffic of this workload as
+                    profiled with rocprofv3 (read from profiles/kernels.json, which names its source),
+  e2e               file to file through the command-line tools in tmpfs (PCIe, file I/O, process
+                    start included) -- a separate figure, never `value`.
 """
 from __future__ import annotations
 
@@ -39,7 +45,10 @@ WORKLOADS = {
     # not a BASELINE config: the shape of a single file (few large blocks), which takes the device-wide
     # forward path and the tiled inverse table build instead of the one-workgroup-per-block kernels
     "acgt-16m-1m": ("acgt", 1024 * 1024, 16 * MIB, 3, "16 MiB ACGT text, 1 MiB blocks: few large blocks (one file)"),
+    # BASELINE configs[0]: the reference's own CPU-runnable case (bytes per GPU = the file's length)
+    "alice29-128k": ("file:alice29.txt", 128 * 1024, 0, 1, "Canterbury alice29.txt, 128 KiB blocks (BASELINE configs[0])"),
 }
+CORPUS = os.path.join(ROOT, "data", "canterbury_corpus")
 DEFAULT_WORKLOAD = "acgt-4g-256k"
 METRIC = "round-trip BWT GB/s at 256KB blocks, 1/8xMI355X; % of HBM roofline"
 
@@ -52,8 +61,16 @@ def cpu_baseline_worker(kind: str, block_size: int, sample: int, seed: int, ncor
     import oracle
     from bwt_amd import synth
 
-    text = open(os.path.join(ROOT, "data", "canterbury_corpus", "alice29.txt"), "rb").read()
-    data = synth.generate(kind, seed, 0, sample, text=text)
+    import numpy as np
+
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    if kind.startswith("file:"):
+        data = np.fromfile(os.path.join(CORPUS, kind[5:]), dtype=np.uint8)
+        what = "the whole file (%d bytes), file to file in tmpfs" % data.size
+    else:
+        data = synth.generate(kind, seed, 0, sample, text=text)
+        what = "first %d MiB of the workload, file to file in tmpfs" % (sample // MIB)
+    sample = int(data.size)
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=shm) as tmp:
         src, fwd, back = (os.path.join(tmp, n) for n in ("in", "fwd", "back"))
@@ -76,7 +93,7 @@ def cpu_baseline_worker(kind: str, block_size: int, sample: int, seed: int, ncor
     print(json.dumps({"value": sample / (t2 - t0) / 1e9, "unit": "GB/s", "cores": len(avail[:ncores]),
                       "kind": kind_name, "forward_s": t1 - t0, "inverse_s": t2 - t1, "roundtrip_ok": ok,
                       "forward_sha256": digest,
-                      "sample": "first %d MiB of the workload, file to file in tmpfs" % (sample // MIB)}))
+                      "sample": what}))
 
 
 def main() -> None:
@@ -90,6 +107,7 @@ def main() -> None:
     ap.add_argument("--kind", default="", help="override the generator kind (exploration only)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run through the command-line tools")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the one-step runs of the other benchmark configurations")
     ap.add_argument("--cpu-baseline-worker", nargs=5, metavar=("KIND", "BS", "SAMPLE", "SEED", "CORES"))
@@ -127,7 +145,7 @@ def main() -> None:
     L = api.lib()
     api.init(0)
     stream = torch.cuda.current_stream().cuda_stream
-    text = open(os.path.join(ROOT, "data", "canterbury_corpus", "alice29.txt"), "rb").read()
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
     d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
 
     def dptr(t):
@@ -142,6 +160,10 @@ def main() -> None:
     def measure(kind, bs, nbytes, cfg, steps, warmup):
         """One workload: generate the shard in HBM, time `steps` forward+inverse passes, verify."""
         seed = synth.base_seed(cfg)
+        file_bytes = None
+        if kind.startswith("file:"):  # a corpus file: every rank transforms the whole file
+            file_bytes = open(os.path.join(CORPUS, kind[5:]), "rb").read()
+            nbytes = len(file_bytes)
         nblocks = L.bwtgpu_num_blocks(nbytes, bs)
         fwd_bytes = nbytes + nblocks
         # ---- shard `rank` of the global synthetic stream, generated in HBM ---------------------
@@ -153,8 +175,11 @@ def main() -> None:
         ws_i = L.bwtgpu_inverse_workspace_bytes(local_rank, fwd_bytes, bs)
         d_ws_f = torch.empty(ws_f, dtype=torch.uint8, device=dev)
         d_ws_i = torch.empty(ws_i, dtype=torch.uint8, device=dev)
-        api.check(L.bwtgpu_synth_device(local_rank, synth.KINDS[kind], seed, rank * nbytes, dptr(d_in), nbytes,
-                                        dptr(d_text), d_text.numel(), stream))
+        if file_bytes is not None:
+            d_in.copy_(torch.frombuffer(bytearray(file_bytes), dtype=torch.uint8))
+        else:
+            api.check(L.bwtgpu_synth_device(local_rank, synth.KINDS[kind], seed, rank * nbytes, dptr(d_in), nbytes,
+                                            dptr(d_text), d_text.numel(), stream))
         # delimiter: lowest byte value absent from the WHOLE dataset = OR of the shards' presence masks
         d_mask = torch.zeros(8, dtype=torch.int32, device=dev)
         api.check(L.bwtgpu_presence_device(local_rank, dptr(d_in), nbytes, dptr(d_mask), stream))
@@ -210,41 +235,96 @@ def main() -> None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         return {"elapsed": elapsed, "fwd_ms": fwd_ms, "inv_ms": inv_ms, "ok": bool(ok.item()),
                 "status": int(status[1]), "phase_share": phase_share, "delim": delim, "nblocks": nblocks,
-                "fwd_bytes": fwd_bytes, "d_fwd": d_fwd, "seed": seed}
+                "fwd_bytes": fwd_bytes, "d_fwd": d_fwd, "seed": seed, "nbytes": nbytes, "d_in": d_in}
+
+    def roofline_entries(name, nbytes, nblocks, fwd_ms, inv_ms):
+        """Both directions of one workload priced at their algorithmic bytes (forward: read N, write
+        N + nblocks; inverse the other way round) over the HIP-event time of the pass on its stream."""
+        algo = 2 * nbytes + nblocks
+        out = {}
+        for key, ms, what in (("roofline", fwd_ms, "forward pass (all its launches: bwt_forward_kernel x2, or the device-wide path for few large blocks)"),
+                              ("roofline_inverse", inv_ms, "inverse pass (all its launches: table build, walk, stitch, place)")):
+            out[key] = {"bound": "hbm", "kernel": what, "achieved": algo / (ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / (ms * 1e-3) / HBM_PEAK,
+                        "traffic": None, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms}
+        t = traffic_table.get(name)
+        if isinstance(t, dict):
+            out["roofline"]["traffic"] = t.get("forward")
+            out["roofline_inverse"]["traffic"] = t.get("inverse")
+        elif t is not None:
+            out["roofline"]["traffic"] = t
+        return out
+
+    def cpu_reference(kind, bs, sample, seed, d_fwd):
+        """The CPU reference on a bounded sample, in a child process; its forward bytes must equal the GPU's."""
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", kind,
+                                  str(bs), str(sample), str(seed), "16"], capture_output=True, text=True,
+                                 timeout=900, check=True).stdout.strip().splitlines()[-1]
+            cpu = json.loads(out)
+            import hashlib
+
+            nb_s = (sample + bs - 1) // bs
+            gpu_prefix = d_fwd[:sample + nb_s].cpu().numpy().tobytes()
+            cpu["gpu_forward_matches"] = (hashlib.sha256(gpu_prefix).hexdigest() == cpu.pop("forward_sha256"))
+            return cpu
+        except Exception as exc:  # the baseline is a reported number, never a reason to lose the GPU line
+            return {"error": str(exc)[:200]}
+
+    def e2e_files(d_in, nbytes, bs):
+        """File to file through the command-line tools in tmpfs, like the reference's own benchmark
+        (reference tests/performance.cpp:84-117): process start, device initialisation, file reads and
+        writes and PCIe both ways are all inside the times.  Never part of `value`."""
+        tools = [os.path.join(ROOT, "build", t) for t in ("bwt", "inverse_bwt")]
+        if not all(os.path.exists(t) for t in tools) or not os.path.isdir("/dev/shm"):
+            return {"error": "build/bwt or build/inverse_bwt or /dev/shm missing"}
+        n = min(nbytes, GIB)
+        try:
+            with tempfile.TemporaryDirectory(dir="/dev/shm") as tmp:
+                src, fwd, back = (os.path.join(tmp, x) for x in ("in", "fwd", "back"))
+                host = d_in[:n].cpu().numpy()
+                host.tofile(src)
+                t0 = time.perf_counter()
+                rc1 = subprocess.run([tools[0], src, fwd, str(bs)], capture_output=True, timeout=300).returncode
+                t1 = time.perf_counter()
+                rc2 = subprocess.run([tools[1], fwd, back, str(bs)], capture_output=True, timeout=300).returncode
+                t2 = time.perf_counter()
+                import numpy as np
+
+                same = rc1 == 0 and rc2 == 0 and bool(np.array_equal(np.fromfile(back, dtype=np.uint8), host))
+            return {"value": n / (t2 - t0) / 1e9, "unit": "GB/s", "bytes": n, "block_size": bs,
+                    "bwt_s": t1 - t0, "inverse_bwt_s": t2 - t1, "roundtrip_verified": same,
+                    "what": "build/bwt then build/inverse_bwt on the first %d MiB of the workload as a file in tmpfs; "
+                            "process start, device initialisation, file I/O and PCIe included" % (n // MIB)}
+        except Exception as exc:
+            return {"error": str(exc)[:200]}
+
+    def load_json(name):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            return {}
+
+    traffic_table = load_json("traffic.json")
+    kernels_table = load_json("kernels.json")
 
     r = measure(kind, bs, nbytes, cfg, args.steps, args.warmup)
     elapsed, fwd_ms, inv_ms, all_ok = r["elapsed"], r["fwd_ms"], r["inv_ms"], r["ok"]
     nblocks, fwd_bytes, delim, d_fwd, seed = r["nblocks"], r["fwd_bytes"], r["delim"], r["d_fwd"], r["seed"]
-    phase_share, status1 = r["phase_share"], r["status"]
+    phase_share, status1, nbytes = r["phase_share"], r["status"], r["nbytes"]
 
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             sample = min(nbytes, args.cpu_sample_mib * MIB)
-            sample -= sample % bs
-            try:
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", kind,
-                                      str(bs), str(sample), str(seed), "16"], capture_output=True, text=True,
-                                     timeout=900, check=True).stdout.strip().splitlines()[-1]
-                cpu = json.loads(out)
-                # the GPU's forward bytes for the same prefix must equal the CPU reference's
-                import hashlib
-
-                nb_s = sample // bs
-                gpu_prefix = d_fwd[:sample + nb_s].cpu().numpy().tobytes()
-                cpu["gpu_forward_matches"] = (hashlib.sha256(gpu_prefix).hexdigest() == cpu.pop("forward_sha256"))
-            except Exception as exc:  # the baseline is a reported number, never a reason to lose the GPU line
-                cpu = {"error": str(exc)[:200]}
+            if sample > bs:
+                sample -= sample % bs
+            cpu = cpu_reference(kind, bs, sample, seed, d_fwd)
+        e2e = None
+        if world == 1 and not args.no_e2e:
+            e2e = e2e_files(r["d_in"], nbytes, bs)
         total_in = nbytes * world
         step_s = elapsed / args.steps
-        algo_fwd = nbytes + fwd_bytes  # forward kernel: reads N, writes N + nblocks
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(args.workload)
-            except Exception:
-                traffic = None
         line = {
             "metric": METRIC,
             "value": total_in / step_s / 1e9,
@@ -261,9 +341,9 @@ def main() -> None:
             "config": {"workload": args.workload, "description": desc, "block_size": bs,
                        "bytes_per_gpu": nbytes, "blocks_per_gpu": nblocks, "delimiter": delim,
                        "parallelism": "block-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "bwt_forward_kernel", "achieved": algo_fwd / (fwd_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo_fwd / (fwd_ms * 1e-3) / HBM_PEAK,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_fwd, "avg_launch_ms": fwd_ms},
+        }
+        line.update(roofline_entries(args.workload, nbytes, nblocks, fwd_ms, inv_ms))
+        line.update({
             "cpu_baseline": cpu,
             "forward_ms": fwd_ms,
             "inverse_ms": inv_ms,
@@ -273,8 +353,10 @@ def main() -> None:
             "roundtrip_verified": all_ok,
             "kernel_status": status1,
             "forward_phase_share": phase_share,
-        }
-    # ---- the other benchmark configurations, one timed step each (same code path) ---------------
+            "kernels": kernels_table.get(args.workload),
+            "e2e": e2e,
+        })
+    # ---- the other benchmark configurations, a few timed steps each (same code path) ------------
     others = []
     if not args.no_other_workloads and not (args.block_size or args.kind or args.bytes_per_gpu):
         del r, d_fwd
@@ -283,12 +365,19 @@ def main() -> None:
             if name == args.workload:
                 continue
             k2, bs2, nb2, cfg2, desc2 = WORKLOADS[name]
-            r2 = measure(k2, bs2, nb2, cfg2, 1, 1)
-            others.append({"workload": name, "block_size": bs2, "bytes_per_gpu": nb2,
-                           "value": nb2 * world / r2["elapsed"] / 1e9, "unit": "GB/s",
-                           "forward_ms": r2["fwd_ms"], "inverse_ms": r2["inv_ms"],
-                           "roundtrip_verified": r2["ok"],
-                           "later_rounds_per_block": r2["phase_share"]["later_rounds_per_block"]})
+            small = k2.startswith("file:") or nb2 <= 64 * MIB  # sub-millisecond passes: more steps
+            r2 = measure(k2, bs2, nb2, cfg2, 20 if small else 3, 2 if small else 1)
+            steps2 = 20 if small else 3
+            entry = {"workload": name, "description": desc2, "block_size": bs2, "bytes_per_gpu": r2["nbytes"],
+                     "steps": steps2, "value": r2["nbytes"] * world * steps2 / r2["elapsed"] / 1e9, "unit": "GB/s",
+                     "forward_ms": r2["fwd_ms"], "inverse_ms": r2["inv_ms"],
+                     "roundtrip_verified": r2["ok"],
+                     "later_rounds_per_block": r2["phase_share"]["later_rounds_per_block"]}
+            entry.update(roofline_entries(name, r2["nbytes"], r2["nblocks"], r2["fwd_ms"], r2["inv_ms"]))
+            if k2.startswith("file:") and rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # the reference's own CPU-runnable case: the CPU reference is timed on the whole file
+                entry["cpu_baseline"] = cpu_reference(k2, bs2, r2["nbytes"], r2["seed"], r2["d_fwd"])
+            others.append(entry)
             all_ok = all_ok and r2["ok"]
             del r2
             torch.cuda.empty_cache()
