@@ -40,7 +40,7 @@ SYMBOLS = [
     "bwtgpu_alloc_host", "bwtgpu_free_host",
     "bwtgpu_pipeline_create", "bwtgpu_pipeline_input", "bwtgpu_pipeline_input_capacity",
     "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
-    "bwtgpu_pipeline_upload_presence", "bwtgpu_forward_batch_static",
+    "bwtgpu_pipeline_upload_presence", "bwtgpu_forward_batch_static", "bwtgpu_time_resident",
 ]
 STATIC_SCRATCH_BYTES = 64 << 20
 
@@ -78,6 +78,9 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_forward_batch.argtypes, L.bwtgpu_forward_batch.restype = [_i, _vp, _sz, _sz, _u8, _vp], _i
     L.bwtgpu_forward_batch_static.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, _vp, _vp]
     L.bwtgpu_forward_batch_static.restype = _i
+    L.bwtgpu_time_resident.argtypes = [_i, _vp, _sz, _sz, _u8, _i, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_double)]
+    L.bwtgpu_time_resident.restype = _i
     L.bwtgpu_inverse_batch_device.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, _vp, _vp, _sz, _vp]
     L.bwtgpu_inverse_batch_device.restype = _i
     L.bwtgpu_inverse_batch.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, ctypes.POINTER(_sz)]

@@ -1021,6 +1021,64 @@ int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total, size_t blo
     return BWTGPU_OK;
 }
 
+int bwtgpu_time_resident(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t delimiter,
+                         int reps, double* forward_ms, double* inverse_ms) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0 || reps < 1) return fail(BWTGPU_ERR_INVALID, "block_size and reps must be greater than 0");
+    if (!in || !forward_ms || !inverse_ms || total_len == 0) return fail(BWTGPU_ERR_INVALID, "null pointer or empty input");
+    if (total_len > ((size_t)1 << 30)) return fail(BWTGPU_ERR_INVALID, "at most 1 GiB per timing call");
+    block_size = forward_block_size(total_len, block_size);
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE) return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu too large", block_size);
+    Device& d = *g_dev[device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    HIP_TRY(hipSetDevice(device));
+    const size_t nb = (total_len + block_size - 1) / block_size, fwd_bytes = total_len + nb;
+    const FwdGeom fg = fwd_geom(d, total_len, block_size);
+    const InvGeom ig = inv_geom(d, fwd_bytes, block_size);
+    if ((rc = grow(&d.d_in, &d.in_cap, total_len))) return rc;
+    if ((rc = grow(&d.d_out, &d.out_cap, fwd_bytes))) return rc;
+    if ((rc = grow(&d.d_ws, &d.ws_cap, std::max(fg.bytes, ig.bytes)))) return rc;
+    if ((rc = grow(&d.d_aux, &d.aux_cap, nb * 4))) return rc;
+    uint8_t* d_back = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (d_back) (void)hipFree(d_back);
+    };
+    if (hipMalloc((void**)&d_back, total_len) != hipSuccess) return fail(BWTGPU_ERR_HIP, "hipMalloc of %zu bytes failed", total_len);
+    for (hipEvent_t& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            cleanup();
+            return fail(BWTGPU_ERR_HIP, "hipEventCreate failed");
+        }
+    auto guarded = [&](int code) {
+        if (code) cleanup();
+        return code;
+    };
+    auto hip_ok = [&](hipError_t e) { return e == hipSuccess ? 0 : fail(BWTGPU_ERR_HIP, "%s", hipGetErrorString(e)); };
+    if ((rc = guarded(hip_ok(hipMemcpyAsync(d.d_in, in, total_len, hipMemcpyHostToDevice, d.stream))))) return rc;
+    float fwd = 0.f, inv = 0.f;
+    for (int dir = 0; dir < 2; ++dir) {
+        for (int it = 0; it <= reps; ++it) {  // pass 0 is the warm-up
+            if (it == 1 && (rc = guarded(hip_ok(hipEventRecord(ev[0], d.stream))))) return rc;
+            rc = dir == 0 ? bwtgpu_forward_batch_device(device, (const uint8_t*)d.d_in, total_len, block_size, delimiter,
+                                                        (uint8_t*)d.d_out, d.d_ws, d.ws_cap, d.stream)
+                          : bwtgpu_inverse_batch_device(device, (const uint8_t*)d.d_out, fwd_bytes, block_size, delimiter,
+                                                        d_back, (uint32_t*)d.d_aux, d.d_ws, d.ws_cap, d.stream);
+            if (guarded(rc)) return rc;
+        }
+        if ((rc = guarded(hip_ok(hipEventRecord(ev[1], d.stream))))) return rc;
+        if ((rc = guarded(hip_ok(hipEventSynchronize(ev[1]))))) return rc;
+        if ((rc = guarded(hip_ok(hipEventElapsedTime(dir == 0 ? &fwd : &inv, ev[0], ev[1]))))) return rc;
+    }
+    cleanup();
+    *forward_ms = (double)fwd / reps;
+    *inverse_ms = (double)inv / reps;
+    return BWTGPU_OK;
+}
+
 int bwtgpu_lowest_clear_bit(const uint32_t presence[8]) {
     for (int v = 0; v < 256; ++v)
         if (!((presence[v >> 5] >> (v & 31)) & 1u)) return v;

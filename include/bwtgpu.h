@@ -170,6 +170,14 @@ int bwtgpu_lowest_clear_bit(const uint32_t presence[8]);
 int bwtgpu_synth_device(int device, int kind, uint64_t seed, uint64_t offset, uint8_t* d_out,
                         size_t len, const uint8_t* d_text, size_t text_len, void* stream);
 
+/* ---- measurement plumbing (reference tests/performance.cpp:84-117 times file to file only) ----
+ * Times the transform with the data resident in device memory: uploads `in` (at most 1 GiB) once, runs
+ * one untimed and `reps` timed forward passes, then the same for the inverse over the forward result,
+ * bracketed by HIP events on the device's stream.  *forward_ms / *inverse_ms receive the mean time of
+ * one pass in milliseconds.  Used by the performance tool for its device-resident columns. */
+int bwtgpu_time_resident(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t delimiter,
+                         int reps, double* forward_ms, double* inverse_ms);
+
 /* ---- pinned host memory for callers that stage their own batches --------------- */
 void* bwtgpu_alloc_host(size_t bytes);
 void bwtgpu_free_host(void* p);

@@ -6,6 +6,13 @@
 // parses), so logs of the two implementations can be compared and plotted side by side.
 // Times include file I/O, the delimiter search and host<->device copies, exactly like the
 // reference's include its own I/O; throughput = input MiB / mean(forward + inverse).
+//
+// Beyond the reference's columns every test also reports the transform with the data resident
+// in device memory (bwtgpu_time_resident: HIP-event time of the forward and inverse passes, GB/s
+// and the share of the 8 TB/s HBM roofline that the round trip's algorithmic bytes -- read N,
+// write N + blocks, and back -- amount to), the GPUs in use and the host's cores.  Those lines
+// start with "GPU", which reference util/plot_performance.py:52-110 skips, and a second aggregate
+// table follows the reference's own.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +21,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bwt.hpp"
@@ -45,7 +53,37 @@ struct Series {
 struct Result {
     Series forward, inverse, total;
     size_t input_size = 0, output_size = 0;
+    double gpu_forward_ms = 0, gpu_inverse_ms = 0;  // data resident in device memory (0: not measured)
+    size_t blocks = 0;
 };
+
+static const double kHbmPeak = 8.0e12;  // bytes per second, MI355X HBM3E
+static int g_devices_bound = 0, g_devices_used = 0;
+
+// Round trip with the file's bytes resident in device memory: mean HIP-event time of a forward and
+// of an inverse pass (files above 1 GiB are skipped: the benchmark corpus is far below that).
+static void measure_resident(const std::string& input, size_t block_size, int trials, Result& r) {
+    if (r.input_size == 0 || r.input_size > ((size_t)1 << 30)) return;
+    std::vector<uint8_t> data(r.input_size);
+    FILE* f = std::fopen(input.c_str(), "rb");
+    if (!f) return;
+    const size_t got = std::fread(data.data(), 1, data.size(), f);
+    std::fclose(f);
+    if (got != data.size()) return;
+    uint32_t mask[8];
+    const int delim = bwtgpu_find_unused_byte(data.data(), data.size(), mask);
+    if (delim < 0) return;
+    double fwd = 0, inv = 0;
+    if (bwtgpu_time_resident(0, data.data(), data.size(), block_size, (uint8_t)delim, trials, &fwd, &inv) != BWTGPU_OK) {
+        std::cerr << "Device-resident timing failed: " << bwtgpu_last_error() << std::endl;
+        return;
+    }
+    r.gpu_forward_ms = fwd;
+    r.gpu_inverse_ms = inv;
+    r.blocks = bwtgpu_num_blocks(data.size(), std::min(block_size, data.size()));
+}
+
+static double roundtrip_algorithmic_bytes(size_t n, size_t blocks) { return 4.0 * (double)n + 2.0 * (double)blocks; }
 
 static double seconds_of(const std::chrono::high_resolution_clock::time_point& a,
                          const std::chrono::high_resolution_clock::time_point& b) {
@@ -84,6 +122,7 @@ static Result measure(const std::string& input, size_t block_size, int trials) {
     }
     std::remove(fwd.c_str());
     std::remove(back.c_str());
+    measure_resident(input, block_size, trials, r);
     return r;
 }
 
@@ -115,6 +154,18 @@ static void print_result(const std::string& name, const Result& r, size_t block_
     print_series("Total Roundtrip:", r.total);
     std::cout << "\nThroughput: " << std::fixed << std::setprecision(2)
               << ((double)r.input_size / (1024.0 * 1024.0)) / r.total.mean() << " MB/s" << std::endl;
+    if (r.gpu_forward_ms > 0 && r.gpu_inverse_ms > 0) {
+        const double sec = (r.gpu_forward_ms + r.gpu_inverse_ms) * 1e-3;
+        std::cout << rule << "\nGPU Forward (data resident in HBM): " << format_time(r.gpu_forward_ms * 1e-3)
+                  << "\nGPU Inverse (data resident in HBM): " << format_time(r.gpu_inverse_ms * 1e-3) << std::endl;
+        std::cout << "GPU Roundtrip Rate: " << std::fixed << std::setprecision(4) << (double)r.input_size / sec / 1e9
+                  << " GB/s" << std::endl;
+        std::cout << "GPU HBM Roofline: " << std::fixed << std::setprecision(4)
+                  << 100.0 * roundtrip_algorithmic_bytes(r.input_size, r.blocks) / sec / kHbmPeak << " % of 8 TB/s"
+                  << std::endl;
+    }
+    std::cout << "GPUs Used: " << g_devices_used << " of " << g_devices_bound
+              << "\nGPU Host Cores: " << std::thread::hardware_concurrency() << std::endl;
     std::cout << bar << std::endl;
 }
 
@@ -140,6 +191,29 @@ static void print_aggregate(const std::map<size_t, std::vector<Result>>& by_bloc
                   << std::setprecision(4) << (in ? (double)out / (double)in : 0.0) << std::endl;
     }
     std::cout << bar << std::endl;
+    // the same dataset with the data resident in device memory
+    std::cout << "\n" << bar << "\nGPU Aggregate by Block Size (data resident in HBM, " << g_devices_used << " of "
+              << g_devices_bound << " GPUs, " << std::thread::hardware_concurrency() << " host cores)\n" << bar << std::endl;
+    std::cout << std::left << std::setw(12) << "Block Size" << std::setw(15) << "Forward" << std::setw(15) << "Inverse"
+              << std::setw(18) << "Roundtrip" << std::setw(14) << "% HBM roofline" << std::endl;
+    std::cout << std::string(74, '-') << std::endl;
+    for (const auto& kv : by_block) {
+        size_t in = 0, blocks = 0;
+        double f = 0, v = 0;
+        for (const Result& r : kv.second) {
+            if (r.gpu_forward_ms <= 0) continue;
+            in += r.input_size;
+            blocks += r.blocks;
+            f += r.gpu_forward_ms * 1e-3;
+            v += r.gpu_inverse_ms * 1e-3;
+        }
+        std::ostringstream tp, pc;
+        tp << std::fixed << std::setprecision(4) << (f + v > 0 ? (double)in / (f + v) / 1e9 : 0.0) << " GB/s";
+        pc << std::fixed << std::setprecision(4) << (f + v > 0 ? 100.0 * roundtrip_algorithmic_bytes(in, blocks) / (f + v) / kHbmPeak : 0.0);
+        std::cout << std::left << std::setw(12) << format_size(kv.first) << std::setw(15) << format_time(f) << std::setw(15)
+                  << format_time(v) << std::setw(18) << tp.str() << std::setw(14) << pc.str() << std::endl;
+    }
+    std::cout << bar << std::endl;
 }
 
 int main(int argc, char* argv[]) {
@@ -160,6 +234,8 @@ int main(int argc, char* argv[]) {
         std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
         return 1;
     }
+    g_devices_bound = devices;
+    g_devices_used = bwt_host::device_budget();
     std::cout << "Dataset Directory: " << dir << "\nNumber of trials per test: " << trials << std::endl;
     std::cout << "Number of worker threads: 1 host thread driving " << bwt_host::device_budget() << " of " << devices
               << " GPU(s)" << std::endl;
