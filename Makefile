@@ -15,9 +15,10 @@ INCLUDES := -Iinclude -I$(HOST)
 LDFLAGS  := -Lbwt_amd -lbwtgpu -Wl,-rpath,'$$ORIGIN/../bwt_amd' -pthread
 
 MAIN_EXECS := $(BUILD)/bwt $(BUILD)/inverse_bwt
-TEST_EXECS := $(BUILD)/test_small $(BUILD)/test_medium
+TEST_EXECS := $(BUILD)/test_small $(BUILD)/test_medium $(BUILD)/test_bzip2_format
 PERF_EXECS := $(BUILD)/performance
-TEST_LIB_OBJS := $(BUILD)/src_test/bwt.o $(BUILD)/src_test/inverse_bwt.o $(BUILD)/src_test/file_processor.o
+TEST_LIB_OBJS := $(BUILD)/src_test/bwt.o $(BUILD)/src_test/inverse_bwt.o $(BUILD)/src_test/file_processor.o \
+                 $(BUILD)/src_test/bzip2_format.o
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/bwtgpu.h
 
 .PHONY: all lib test performance clean rebuild

@@ -41,6 +41,7 @@ SYMBOLS = [
     "bwtgpu_pipeline_create", "bwtgpu_pipeline_input", "bwtgpu_pipeline_input_capacity",
     "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
     "bwtgpu_pipeline_upload_presence", "bwtgpu_forward_batch_static", "bwtgpu_time_resident",
+    "bwtgpu_inverse_origin_workspace_bytes", "bwtgpu_inverse_origin_batch_device", "bwtgpu_inverse_origin_batch",
 ]
 STATIC_SCRATCH_BYTES = 64 << 20
 
@@ -81,6 +82,12 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_time_resident.argtypes = [_i, _vp, _sz, _sz, _u8, _i, ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(ctypes.c_double)]
     L.bwtgpu_time_resident.restype = _i
+    L.bwtgpu_inverse_origin_workspace_bytes.argtypes = [_i, _sz, _sz]
+    L.bwtgpu_inverse_origin_workspace_bytes.restype = _sz
+    L.bwtgpu_inverse_origin_batch_device.argtypes = [_i, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]
+    L.bwtgpu_inverse_origin_batch_device.restype = _i
+    L.bwtgpu_inverse_origin_batch.argtypes = [_i, _vp, _sz, _sz, _vp, _vp]
+    L.bwtgpu_inverse_origin_batch.restype = _i
     L.bwtgpu_inverse_batch_device.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, _vp, _vp, _sz, _vp]
     L.bwtgpu_inverse_batch_device.restype = _i
     L.bwtgpu_inverse_batch.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, ctypes.POINTER(_sz)]
@@ -233,6 +240,66 @@ def bwt_inverse_process_file(input_file: str, output_file: str, block_size: int)
             return 1
         try:
             out.write(inverse_batch(raw[1:], block_size, int(raw[0])))
+        except BwtGpuError as e:
+            print("Error: " + str(e), file=sys.stderr)
+            return 1
+    return 0
+
+
+# ---- origin-pointer blocks: the container of the reference's bzip2 comparison tool ------------
+def inverse_origin_batch(last_columns, block_size: int, orig_ptrs, device: int = 0) -> bytes:
+    """Last columns of sorted rotations (block i at i*block_size) + the row of each block's text
+    -> the texts (reference util/bzip2_bwt_utils.cpp:200-253, for a whole batch)."""
+    a = _as_u8(last_columns)
+    p = np.ascontiguousarray(orig_ptrs, dtype=np.uint32)
+    if block_size <= 0:
+        raise BwtGpuError(ERR_INVALID, "block_size must be greater than 0")
+    if p.size != (a.size + block_size - 1) // block_size:
+        raise BwtGpuError(ERR_INVALID, "one origin row per block expected")
+    out = np.empty(max(1, a.size), dtype=np.uint8)
+    check(lib().bwtgpu_inverse_origin_batch(device, a.ctypes.data if a.size else None, a.size, block_size,
+                                            p.ctypes.data if p.size else None, out.ctypes.data))
+    return out[:a.size].tobytes()
+
+
+def parse_origin_container(raw, block_size: int):
+    """Splits the container (per block: 0xFF, origin row as three bytes big-endian, the last column;
+    reference util/bzip2_bwt_utils.cpp:157-198) into (last columns back to back, origin rows).  Like
+    the reference's reader it stops, keeping the blocks before, at a wrong marker, a cut header, or
+    a row outside its block."""
+    a = _as_u8(raw)
+    cols, rows, r = [], [], 0
+    while r < a.size:
+        if a[r] != 0xFF or a.size - r < 4:
+            break
+        orig = (int(a[r + 1]) << 16) | (int(a[r + 2]) << 8) | int(a[r + 3])
+        n = min(block_size, a.size - r - 4)
+        if n == 0 or orig >= n:
+            break
+        cols.append(a[r + 4:r + 4 + n])
+        rows.append(orig)
+        r += 4 + n
+    last = np.concatenate(cols) if cols else np.empty(0, dtype=np.uint8)
+    return last, np.asarray(rows, dtype=np.uint32)
+
+
+def bzip2_format_inverse_process_file(input_file: str, output_file: str, block_size: int) -> int:
+    """reference util/bzip2_bwt_utils.cpp:316-349 (Bzip2BWTProcessor::process_file_inverse)."""
+    try:
+        with open(input_file, "rb") as f:
+            raw = np.frombuffer(f.read(), dtype=np.uint8)
+    except OSError:
+        print("Error: Cannot open input file: " + input_file, file=sys.stderr)
+        return 1
+    try:
+        out = open(output_file, "wb")
+    except OSError:
+        print("Error: Cannot open output file: " + output_file, file=sys.stderr)
+        return 1
+    with out:
+        last, rows = parse_origin_container(raw, block_size)
+        try:
+            out.write(inverse_origin_batch(last, block_size, rows) if last.size else b"")
         except BwtGpuError as e:
             print("Error: " + str(e), file=sys.stderr)
             return 1

@@ -113,6 +113,14 @@ struct InvArgs {
     // splitter map row -> row * mul mod n and its inverse id -> id * inv mod n; [0] for full
     // blocks (n = block_size + 1), [1] for the last block of the batch
     uint32_t split_mul[2], split_inv[2];
+    // Origin-pointer blocks (the container of reference util/bzip2_bwt_utils.cpp:137-198): the last
+    // column of the sorted ROTATIONS of the text, no delimiter; orig_ptr[b] is the row of the text
+    // itself.  Null for the delimiter format.  Such a block has n = text length rows; the kernels
+    // treat row orig_ptr[b] as they treat the delimiter row (it starts and ends the chain and its byte
+    // is left out), which yields the text's first n - 1 bytes; bwt_inverse_origin_finish_kernel adds
+    // the last one.  `delim` is 256 then (no byte matches it).
+    const uint32_t* orig_ptr;
+    uint32_t out_stride;  // block b's text starts at out + b * out_stride (block_size; origin-pointer blocks: block_size + 1)
 };
 
 template <int NT>
@@ -226,8 +234,12 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         for (int i = 0; i < W; ++i)
             if (sh.drow[i] != kNoRow) drow = sh.drow[i];
         // split the walk only when it is the plain single-delimiter case and long enough to pay
-        const uint32_t mode = drow == kNoRow ? kModeNone
-                              : (sh.ndelim == 1u && n >= a.multi_min_rows) ? kModeMulti : kModeSingle;
+        uint32_t mode = drow == kNoRow ? kModeNone
+                        : (sh.ndelim == 1u && n >= a.multi_min_rows) ? kModeMulti : kModeSingle;
+        if (a.orig_ptr) {  // the chain starts at the given row; a row outside the block is refused
+            drow = a.orig_ptr[b] < n ? a.orig_ptr[b] : kNoRow;
+            mode = drow == kNoRow ? kModeNone : n >= a.multi_min_rows ? kModeMulti : kModeSingle;
+        }
         if (tid == 0) {
             a.drow[b] = drow;
             a.mode[b] = mode;
@@ -356,8 +368,12 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, I
         if (tid < 256) s_base[tid] = c0 + before;
     }
     const uint32_t dlast = ta.dacc[2u * b], ndelim = ta.dacc[2u * b + 1u];
-    const uint32_t drow = dlast ? dlast - 1u : kNoRow;
-    const uint32_t mode = drow == kNoRow ? kModeNone : (ndelim == 1u && n >= a.multi_min_rows) ? kModeMulti : kModeSingle;
+    uint32_t drow = dlast ? dlast - 1u : kNoRow;
+    uint32_t mode = drow == kNoRow ? kModeNone : (ndelim == 1u && n >= a.multi_min_rows) ? kModeMulti : kModeSingle;
+    if (a.orig_ptr) {
+        drow = a.orig_ptr[b] < n ? a.orig_ptr[b] : kNoRow;
+        mode = drow == kNoRow ? kModeNone : n >= a.multi_min_rows ? kModeMulti : kModeSingle;
+    }
     if (t == 0 && tid == 0) {
         a.drow[b] = drow;
         a.mode[b] = mode;
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
         return;
     }
     const TW* __restrict__ T = (const TW*)a.T + (uint64_t)b * a.tstride;
-    uint8_t* const o = a.out + (uint64_t)b * a.block_size;
+    uint8_t* const o = a.out + (uint64_t)b * a.out_stride;
     BackWriter bw;
     bw.init(o + len);
     row = TableWord<TW>::row(T[row]);
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     const uint8_t* src = a.stage + (sb + j) * a.slot;
     uint32_t c = 0;
     BackWriter bw;
-    bw.init(a.out + (uint64_t)b * a.block_size + (n - 1) - pos);
+    bw.init(a.out + (uint64_t)b * a.out_stride + (n - 1) - pos);
     // Source byte t goes to address end - 1 - t.  The bytes down to the first dword boundary go
     // one by one; from there every aligned destination dword is four consecutive source bytes
     // reversed: an unaligned source dword (funnel shift over two aligned ones) byte-swapped.
@@ -813,6 +829,33 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
         prev = v.w;
     }
     bw.flush();
+}
+
+// ---- origin-pointer blocks: the last step --------------------------------------------------------
+// The walk kernels have produced, below out + b * out_stride + n - 1, the bytes of the rows that follow
+// orig_ptr[b] on its cycle of the LF permutation: c - 1 bytes, where c is the cycle's length
+// (lens[b] = c - 1).  The text's last byte is the origin row's own (reference
+// util/bzip2_bwt_utils.cpp:243-247 emits it first and reverses), and when the text is a shorter
+// string repeated (c < n: the rotations tie and the LF permutation falls into n / c cycles) the walk of
+// the reference goes round the cycle n / c times: the text is its last c bytes repeated.
+__global__ __launch_bounds__(256) void bwt_inverse_origin_finish_kernel(InvArgs a) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = inv_block_len(a, b);
+    const uint32_t have = a.lens[b];
+    if (a.mode[b] == kModeNone || have >= n) {  // workgroup-uniform
+        if (threadIdx.x == 0) a.lens[b] = BWTGPU_LEN_NO_DELIMITER;
+        return;
+    }
+    const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
+    uint8_t* const o = a.out + (uint64_t)b * a.out_stride;
+    const uint32_t c = have + 1u;
+    if (threadIdx.x == 0) o[n - 1u] = L[a.drow[b]];
+    __syncthreads();
+    const uint8_t* __restrict__ cyc = o + (n - c);
+    const uint32_t shift = (n - c) % c;  // position i < n - c equals position n - c + ((i - (n - c)) mod c)
+    for (uint32_t i = threadIdx.x; i < n - c; i += blockDim.x) o[i] = cyc[(i % c + c - shift) % c];
+    __syncthreads();
+    if (threadIdx.x == 0) a.lens[b] = n;
 }
 
 }  // namespace bwtgpu

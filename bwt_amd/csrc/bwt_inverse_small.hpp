@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kInvSmallWaves* kWave) void bwt_inverse_small_kerne
     for (uint32_t b = blockIdx.x * (uint32_t)kInvSmallWaves + (uint32_t)wave_id(); b < a.nblocks; b += nwaves) {
         const uint32_t n = inv_block_len(a, b);
         const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
-        uint8_t* const o = a.out + (uint64_t)b * a.block_size;
+        uint8_t* const o = a.out + (uint64_t)b * a.out_stride;
         const int nv = (int)((n + kWave - 1u) / kWave);  // wave-uniform
         for (int i = lane; i < 256; i += kWave) sh.hist[i] = 0;
         compiler_fence();

@@ -818,9 +818,15 @@ int bwtgpu_forward_batch_static(int device, const uint8_t* d_in, size_t total_le
     return BWTGPU_OK;
 }
 
-int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, size_t block_size,
-                                uint8_t delimiter, uint8_t* d_out, uint32_t* d_out_lens, void* d_workspace,
-                                size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+namespace {
+// Both inverse entry points: delimiter blocks (d_orig_ptr null; chunks of block_size + 1 bytes) and
+// origin-pointer blocks (chunks of block_size + 1 bytes as well: the caller passes the container's
+// block size minus one, so that a chunk is one block's last column; `delimiter` is 256 then).
+int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_size, uint32_t delimiter,
+                   const uint32_t* d_orig_ptr, uint8_t* d_out, uint32_t* d_out_lens, void* d_workspace,
+                   size_t workspace_bytes, void* stream) {
     int rc = check_device(device);
     if (rc) return rc;
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
@@ -846,6 +852,8 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.block_size = (uint32_t)block_size;
     a.nblocks = (uint32_t)g.nblocks;
     a.delim = delimiter;
+    a.orig_ptr = d_orig_ptr;
+    a.out_stride = (uint32_t)block_size + (d_orig_ptr ? 1u : 0u);
     a.tstride = g.tstride;
     a.seg_cap = g.seg_cap;
     a.split_shift = g.split_shift;
@@ -871,7 +879,7 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
     a.pool = ws + g.pool_off;
     a.lens = d_out_lens;
     a.queue = (uint32_t*)d_workspace;
-    if (block_size + 1 <= (size_t)kInvSmallCap) {  // small blocks: one wave per block, everything in LDS
+    if (block_size + 1 <= (size_t)kInvSmallCap && !d_orig_ptr) {  // small blocks: one wave per block, everything in LDS
         const size_t wgs = (g.nblocks + kInvSmallWaves - 1) / kInvSmallWaves;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 8));
         hipLaunchKernelGGL(bwt_inverse_small_kernel, dim3(grid), dim3(kInvSmallWaves * kWave), 0, s, a);
@@ -915,7 +923,46 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, s
         hipLaunchKernelGGL(bwt_inverse_place_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
+    if (d_orig_ptr) {
+        hipLaunchKernelGGL(bwt_inverse_origin_finish_kernel, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
     return BWTGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total, size_t block_size,
+                                uint8_t delimiter, uint8_t* d_out, uint32_t* d_out_lens, void* d_workspace,
+                                size_t workspace_bytes, void* stream) {
+    return inverse_launch(device, d_in, total, block_size, delimiter, nullptr, d_out, d_out_lens, d_workspace,
+                          workspace_bytes, stream);
+}
+
+size_t bwtgpu_inverse_origin_workspace_bytes(int device, size_t total_len, size_t block_size) {
+    if (check_device(device) || block_size < 2 || total_len == 0) return 0;
+    return inv_geom(*g_dev[device], total_len, std::min(block_size, total_len) - 1).bytes;
+}
+
+int bwtgpu_inverse_origin_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                       const uint32_t* d_orig_ptr, uint8_t* d_out, uint32_t* d_out_lens,
+                                       void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (total_len == 0) return BWTGPU_OK;
+    if (!d_orig_ptr) return fail(BWTGPU_ERR_INVALID, "null origin-pointer array");
+    block_size = std::min(block_size, total_len);
+    if (block_size == 1) {  // one-byte blocks are their own transform (and have no room for a table row)
+        int rc = check_device(device);
+        if (rc) return rc;
+        if (!d_in || !d_out || !d_out_lens) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemcpyAsync(d_out, d_in, total_len, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_out_lens, 1, total_len, (hipStream_t)stream));
+        return BWTGPU_OK;
+    }
+    return inverse_launch(device, d_in, total_len, block_size - 1, 256u, d_orig_ptr, d_out, d_out_lens, d_workspace,
+                          workspace_bytes, stream);
 }
 
 int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t delimiter,
@@ -1018,6 +1065,48 @@ int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total, size_t blo
         off += sub;
     }
     if (out_len) *out_len = written;
+    return BWTGPU_OK;
+}
+
+int bwtgpu_inverse_origin_batch(int device, const uint8_t* in, size_t total_len, size_t block_size,
+                                const uint32_t* orig_ptr, uint8_t* out) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (total_len == 0) return BWTGPU_OK;
+    if (!in || !out || !orig_ptr) return fail(BWTGPU_ERR_INVALID, "null host pointer");
+    block_size = std::min(block_size, total_len);
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE) return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu too large", block_size);
+    Device& d = *g_dev[device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    HIP_TRY(hipSetDevice(device));
+    const size_t max_sub = std::max<size_t>(block_size, (size_t)1 << 30);
+    const size_t blocks_per_sub = std::max<size_t>(1, max_sub / block_size);
+    std::vector<uint32_t> lens;
+    for (size_t off = 0; off < total_len;) {
+        const size_t sub = std::min(total_len - off, blocks_per_sub * block_size);
+        const size_t nb = (sub + block_size - 1) / block_size, b0 = off / block_size;
+        const size_t ws = block_size > 1 ? inv_geom(d, sub, std::min(block_size, sub) - 1).bytes : 256;
+        if ((rc = grow(&d.d_in, &d.in_cap, sub))) return rc;
+        if ((rc = grow(&d.d_out, &d.out_cap, sub))) return rc;
+        if ((rc = grow(&d.d_ws, &d.ws_cap, ws))) return rc;
+        if ((rc = grow(&d.d_aux, &d.aux_cap, nb * 8))) return rc;
+        uint32_t* d_ptr = (uint32_t*)d.d_aux;
+        uint32_t* d_lens = d_ptr + nb;
+        HIP_TRY(hipMemcpyAsync(d.d_in, in + off, sub, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(d_ptr, orig_ptr + b0, nb * 4, hipMemcpyHostToDevice, d.stream));
+        rc = bwtgpu_inverse_origin_batch_device(device, (const uint8_t*)d.d_in, sub, block_size, d_ptr, (uint8_t*)d.d_out,
+                                                d_lens, d.d_ws, d.ws_cap, d.stream);
+        if (rc) return rc;
+        lens.resize(nb);
+        HIP_TRY(hipMemcpyAsync(lens.data(), d_lens, nb * 4, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipMemcpyAsync(out + off, d.d_out, sub, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        for (size_t b = 0; b < nb; ++b)
+            if (lens[b] == BWTGPU_LEN_NO_DELIMITER)
+                return fail(BWTGPU_ERR_INVALID, "block %zu: origin pointer %u outside the block", b0 + b, orig_ptr[b0 + b]);
+        off += sub;
+    }
     return BWTGPU_OK;
 }
 

@@ -125,6 +125,22 @@ int bwtgpu_inverse_batch_device(int device, const uint8_t* d_in, size_t total_le
 int bwtgpu_inverse_batch(int device, const uint8_t* in, size_t total_len_with_delims,
                          size_t block_size, uint8_t delimiter, uint8_t* out, size_t* out_len);
 
+/* ---- inverse of origin-pointer blocks: the block format of the reference's bzip2 comparison tool
+ *      (reference util/bzip2_bwt_utils.cpp:137-198 container, :200-253 inverse).  A block of len text
+ *      bytes is the last column of its len sorted ROTATIONS (no delimiter, len bytes) plus the row of
+ *      the text itself.  `in` holds the last columns back to back (block i at in + i*block_size, the
+ *      last one possibly shorter), orig_ptr[i] the rows; block i's text goes to out + i*block_size.
+ *      The container's framing (0xFF, 3-byte big-endian row, last column) is the host layer's
+ *      business.  A row outside its block fails with BWTGPU_ERR_INVALID (the reference stops reading
+ *      there, :189-192); d_out_lens[i] receives the block's length, or BWTGPU_LEN_NO_DELIMITER for such
+ *      a block.  Same kernels as the delimiter format: the given row plays the delimiter row's part. */
+size_t bwtgpu_inverse_origin_workspace_bytes(int device, size_t total_len, size_t block_size);
+int bwtgpu_inverse_origin_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                       const uint32_t* d_orig_ptr, uint8_t* d_out, uint32_t* d_out_lens,
+                                       void* d_workspace, size_t workspace_bytes, void* stream);
+int bwtgpu_inverse_origin_batch(int device, const uint8_t* in, size_t total_len, size_t block_size,
+                                const uint32_t* orig_ptr, uint8_t* out);
+
 /* ---- slab pipeline: replaces the reader -> BlockingQueue -> workers -> ReorderBuffer ->
  *      writer threads of reference src/bwt.cpp:183-233 (and the serial read/transform/write
  *      loop of src/inverse_bwt.cpp:85-95).  The caller fills a pinned input slab with whole

@@ -159,3 +159,86 @@ def reference() -> _Reference:
             raise FileNotFoundError(_REF_SO + " (build it where the reference checkout exists: make -C oracle ref)")
         _reference = _Reference()
     return _reference
+
+
+class _OriginOracle:
+    """ctypes view of liborigin_oracle.so: the origin-pointer block format of the reference's bzip2
+    comparison tool (reference util/bzip2_bwt_utils.cpp:137-253).  Parity unpinned: the reference
+    holds no vectors for it and its forward half needs bzip2's sources, which are absent."""
+
+    def __init__(self) -> None:
+        so = os.path.join(_HERE, "liborigin_oracle.so")
+        if not os.path.exists(so):
+            build()
+        lib = ctypes.CDLL(so)
+        lib.oracle_origin_forward.argtypes = [_u8p, ctypes.c_size_t, _u8p]
+        lib.oracle_origin_forward.restype = ctypes.c_long
+        lib.oracle_origin_inverse.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_size_t, _u8p]
+        lib.oracle_origin_inverse.restype = ctypes.c_int
+        lib.oracle_origin_inverse_buffer.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_size_t, _u8p]
+        lib.oracle_origin_inverse_buffer.restype = ctypes.c_long
+        self.lib = lib
+
+    def forward_slow(self, data: bytes):
+        """(last column, origin row) by comparing whole rotations: small blocks only."""
+        out = (ctypes.c_uint8 * max(1, len(data)))()
+        orig = self.lib.oracle_origin_forward(_buf(data), len(data), out)
+        return bytes(out)[:len(data)], int(orig)
+
+    @staticmethod
+    def forward(data: bytes):
+        """(last column, origin row) of one block: rotations ordered by rank doubling over cyclic
+        positions (numpy), equal rotations by position -- the same result as forward_slow."""
+        import numpy as np
+
+        n = len(data)
+        if n == 0:
+            return b"", 0
+        s = np.frombuffer(data, dtype=np.uint8)
+        rank = s.astype(np.int64)
+        idx = np.arange(n, dtype=np.int64)
+        h = 1
+        while True:
+            key = rank * (int(rank.max()) + 2) + rank[(idx + h) % n]
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            new = np.empty(n, dtype=np.int64)
+            new[order] = np.concatenate(([0], np.cumsum(ks[1:] != ks[:-1])))
+            rank = new
+            if int(rank.max()) == n - 1 or h >= n:
+                break
+            h *= 2
+        order = np.argsort(rank, kind="stable")
+        last = s[(order - 1) % n].tobytes()
+        return last, int(np.nonzero(order == 0)[0][0])
+
+    def forward_buffer(self, data: bytes, block_size: int) -> bytes:
+        """The container: per block 0xFF, the origin row in three bytes big-endian, the last column."""
+        out = bytearray()
+        for off in range(0, len(data), block_size):
+            last, orig = self.forward(data[off:off + block_size])
+            out += bytes([0xFF, (orig >> 16) & 255, (orig >> 8) & 255, orig & 255]) + last
+        return bytes(out)
+
+    def inverse(self, last: bytes, orig: int) -> bytes:
+        out = (ctypes.c_uint8 * max(1, len(last)))()
+        if self.lib.oracle_origin_inverse(_buf(last), len(last), orig, out):
+            raise ValueError("origin row outside the block")
+        return bytes(out)[:len(last)]
+
+    def inverse_buffer(self, data: bytes, block_size: int) -> bytes:
+        out = (ctypes.c_uint8 * max(1, len(data)))()
+        r = self.lib.oracle_origin_inverse_buffer(_buf(data), len(data), block_size, out)
+        if r < 0:
+            raise MemoryError
+        return bytes(out)[:r]
+
+
+_origin = None
+
+
+def origin() -> _OriginOracle:
+    global _origin
+    if _origin is None:
+        _origin = _OriginOracle()
+    return _origin

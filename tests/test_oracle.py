@@ -139,3 +139,32 @@ def test_oracle_equals_compiled_reference(orc, tmp_path):
         assert ref.forward_file(src, a, bs) == 0 and orc.forward_file(src, b, bs, 4) == 0
         assert open(a, "rb").read() == open(b, "rb").read()
         assert ref.find_unique_char(src) == orc.find_unique_byte(open(src, "rb").read())
+
+
+def test_origin_pointer_oracle():
+    """The CPU restatement of the origin-pointer format (reference util/bzip2_bwt_utils.cpp:137-253;
+    parity unpinned: the reference holds no vectors for it): the textbook answer for "banana", the
+    rank-doubling forward equal to the rotation-comparing one, and the inverse undoing both."""
+    import random
+
+    o = oracle.origin()
+    assert o.forward(b"banana") == (b"nnbaaa", 3) == o.forward_slow(b"banana")
+    assert o.inverse(b"nnbaaa", 3) == b"banana"
+    rng = random.Random(5)
+    for _ in range(200):
+        n = rng.randint(1, 300)
+        s = bytes(rng.randrange(97, 97 + rng.choice([1, 2, 4, 26])) for _ in range(n))
+        if rng.random() < 0.3:  # a shorter string repeated: equal rotations
+            p = rng.randint(1, max(1, n // 2))
+            s = (s[:p] * (n // p + 1))[:n]
+        a = o.forward(s)
+        assert a == o.forward_slow(s)
+        assert o.inverse(*a) == s
+    data = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()[:50000]
+    for bs in (1, 999, 50000):
+        box = o.forward_buffer(data, bs)
+        assert len(box) == len(data) + 4 * ((len(data) + bs - 1) // bs)
+        assert o.inverse_buffer(box, bs) == data
+    assert o.inverse_buffer(b"\x00abc", 3) == b""  # wrong marker: nothing is read
+    with pytest.raises(ValueError):
+        o.inverse(b"abc", 3)
