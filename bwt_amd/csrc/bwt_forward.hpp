@@ -74,7 +74,8 @@ constexpr int kFineBits = 13;        // round 0: the top bits of the key that ch
 constexpr int kFine = 1 << kFineBits;
 constexpr int kLdsDigitBits = 4;     // digit width of the LDS bucket sort
 constexpr int kMaxBuckets = 256;     // round-0 buckets per block (bucket ids are bytes in the lookup table)
-constexpr size_t kBucketDirBytes = 2 * (kMaxBuckets + 1) * sizeof(uint32_t);  // bucket directory after the rank array
+// after the rank array: the bucket directory and the first sorted row of every fine bin
+constexpr size_t kBucketDirBytes = (2 * (kMaxBuckets + 1) + kFine + 1) * sizeof(uint32_t);
 constexpr uint32_t kBucketTarget = 4100;  // elements per bucket the partition aims at (64 buckets cover 256 KiB + 1)
 
 // Per-phase time accounting (100 MHz constant clock), summed over workgroups into
@@ -798,6 +799,7 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit&
 struct BucketDir {
     uint32_t* start;   // [nb + 1]
     uint32_t* flo;     // [nb + 1]
+    uint32_t* fstart;  // [kFine + 1]: sorted row of the first element of every fine bin ([kFine] = n)
     uint32_t nb;       // number of bucket ids (some may be empty)
 };
 
@@ -834,8 +836,10 @@ __device__ __forceinline__ void assign_buckets(FwdShared<NT>& sh, uint32_t n, ui
             atomicMin(&tflo[id], f);
         }
         sh.v.lut[f] = (uint8_t)id;
+        dir.fstart[f] = run;
         run += c;
     }
+    if (tid == 0) dir.fstart[kFine] = n;
     __syncthreads();
     if (w == 0) {  // suffix minima, so an empty bucket id reads as an empty range
         uint32_t cs = n, cf = 1u << fbits;
@@ -1038,12 +1042,18 @@ __device__ __forceinline__ void rerank(const uint64_t* __restrict__ cur, uint64_
 // counts of the block and are advanced.  The elements in LDS are still shifted left by `up`
 // and lack `bsub` (see lds_sort_bucket).  A first sweep finds the run heads and tails of every
 // 64-element vector (kept as ballots in v.cw) and counts; the second one acts on them.
+// `narrow` (fshift >= 0): instead of the bucket itself only the low fshift bits of every key are written
+// back, as one 32-bit word per sorted row, to nk[s0 ..] -- together with the fine bins' first rows that
+// is all a later rank lookup needs (ranks_by_fine_search).  A bucket in which more than a sixteenth
+// of the suffixes stay tied then writes the ranks of its finished suffixes too (text: the block is
+// going to need all ranks); `skipped` tells the caller whether any bucket did not.
 template <int NT>
-__device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t s0, uint32_t cnt,
+__device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t* __restrict__ nk, int fshift,
+                                              uint32_t s0, uint32_t cnt,
                                               uint64_t* __restrict__ nxt, uint32_t* __restrict__ rank,
                                               uint8_t* __restrict__ out, int ibits, int kshift, int gshift,
                                               int up, uint64_t bsub, bool all_ranks, FwdShared<NT>& sh,
-                                              uint32_t& m_tot, uint32_t& g_tot) {
+                                              uint32_t& m_tot, uint32_t& g_tot, bool& skipped) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
     const uint64_t* ls = sh.u.lsort;
@@ -1118,6 +1128,12 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
         totA += ca;
         totG += cg;
     }
+    const bool narrow = fshift >= 0;
+    const uint32_t fmask = narrow ? (uint32_t)((1ull << fshift) - 1ull) : 0u;
+    if (narrow && !all_ranks) {
+        all_ranks = totA * 16u > cnt;  // workgroup-uniform
+        if (!all_ranks) skipped = true;
+    }
     {
         uint32_t v = 0;
         for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave, v += U) {
@@ -1144,7 +1160,10 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
                     const bool act = valid && !single;
                     const uint64_t A = __ballot(valid) & ~(H & T), NS = H & ~T;
                     const uint32_t idx = (uint32_t)(ec & imask);
-                    if (valid) g[k] = ec;
+                    if (valid) {
+                        if (narrow) nk[s0 + k] = (uint32_t)(ec >> kshift) & fmask;
+                        else g[k] = ec;
+                    }
                     if (single) out[s0 + k] = (uint8_t)(ec >> ibits);
                     if (all_ranks && single) rank[idx] = s0 + k;
                     if (act) {
@@ -1215,6 +1234,77 @@ __device__ __forceinline__ void ranks_by_search(const uint64_t* __restrict__ sor
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) out[u] = lo[u];
+}
+
+// The same lookup without the sorted round-0 array: the key's top bits name a fine bin, whose rows
+// fstart[f] .. fstart[f + 1] are known from the counting sweep, and inside the bin the rows are
+// ordered by the low fshift key bits, which the fused rerank has left in nk[row] (one word per row).
+// A dozen rows to search instead of the whole block, all in one or two cache lines.
+struct FineIndex {
+    const uint32_t* fstart;
+    const uint32_t* nk;
+    int fshift;
+};
+
+// out[u] = first row whose key is not below that of suffix j[u]; alone[u] = no other suffix shares the
+// key (meaningful for j[u] < n, whose own element is in the array).
+template <int U>
+__device__ __forceinline__ void ranks_by_fine_search(const FineIndex& fx, const Round0& r, const uint8_t* sym,
+                                                     const uint32_t (&j)[U], uint32_t (&out)[U], bool (&alone)[U]) {
+    uint64_t key[U];
+    suffix_keys<U>(r, sym, j, key);
+    const uint32_t fmask = (uint32_t)((1ull << fx.fshift) - 1ull);
+    uint32_t lo[U], hi[U], end[U], res[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t f = min((uint32_t)(key[u] >> fx.fshift), (uint32_t)kFine - 1u);
+        lo[u] = fx.fstart[f];
+        hi[u] = end[u] = fx.fstart[f + 1u];
+        res[u] = (uint32_t)key[u] & fmask;
+    }
+    for (int it = 0; it <= r.ibits; ++it) {
+        bool open = false;
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            open = open || lo[u] < hi[u];
+            v[u] = fx.nk[min((lo[u] + hi[u]) >> 1, r.n - 1u)];
+        }
+        if (__ballot(open) == 0ull) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t mid = (lo[u] + hi[u]) >> 1;
+            if (lo[u] < hi[u]) {
+                if (v[u] < res[u]) lo[u] = mid + 1;
+                else hi[u] = mid;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        out[u] = lo[u];
+        alone[u] = lo[u] + 1u >= end[u] || fx.nk[min(lo[u] + 1u, r.n - 1u)] != res[u];
+    }
+}
+
+// Completes the rank array after a fused round 0 that wrote ranks only for the suffixes still tied
+// (and for whole buckets of text-like data): every suffix that is alone with its round-0 key gets
+// its row, found through the fine index; the others keep the ranks the rounds so far have given them.
+template <int NT>
+__device__ __noinline__ void fill_unique_ranks(const FineIndex& fx, const Round0& r, const uint8_t* sym,
+                                               uint32_t* __restrict__ rank) {
+    constexpr int U = 4;
+    for (uint32_t base = 0; base < r.n; base += U * NT) {
+        uint32_t j[U], rk[U];
+        bool alone[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) j[u] = base + (uint32_t)(u * NT) + threadIdx.x;
+        ranks_by_fine_search<U>(fx, r, sym, j, rk, alone);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j[u] < r.n && alone[u]) rank[j[u]] = rk[u];
+    }
+    __syncthreads();
 }
 
 // ---- doubling rounds inside LDS ---------------------------------------------------------------
@@ -2366,6 +2456,7 @@ restart:
     dir.start = rank + a.ncap;
     const uint32_t target = max(kBucketTarget, (n + (uint32_t)kMaxBuckets - 1u) / (uint32_t)kMaxBuckets);
     dir.flo = dir.start + (kMaxBuckets + 1);
+    dir.fstart = dir.flo + (kMaxBuckets + 1);
     assign_buckets<NT>(sh, n, target, fbits, dir);
     bool fused = true;  // every bucket fits LDS
     uint32_t longest_bucket = 0;
@@ -2420,6 +2511,13 @@ restart:
     // When every bucket fits LDS the rerank is done on the sorted bucket while it is still
     // there (survivor ranks only); otherwise, or when many suffixes survive, a separate sweep does it.
     uint32_t m = 0, G = 0;
+    // With the rerank fused, the sorted buckets are not written back: one word per row with the key
+    // bits below the fine bin goes into the same buffer (row r at word r: always inside the part of the
+    // buffer whose buckets have been consumed), which is what rank lookups need (FineIndex).
+    const bool narrow = fused && r0.fshift <= 32;
+    uint32_t* const nk = reinterpret_cast<uint32_t*>(sorted0);
+    const FineIndex fx{dir.fstart, nk, r0.fshift};
+    bool ranks_skipped = false;
     for (uint32_t k = 0; k < dir.nb; ++k) {
         const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
         if (cnt == 0) continue;  // workgroup-uniform
@@ -2431,7 +2529,7 @@ restart:
             uint64_t bsub;
             lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh, up, bsub);
             pc.lap(12);
-            if (fused) rerank_bucket<NT>(sorted0 + s0, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic, sh, m, G);
+            if (fused) rerank_bucket<NT>(sorted0 + s0, nk, narrow ? r0.fshift : -1, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic, sh, m, G, ranks_skipped);
             else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
             pc.lap(10);
         }
@@ -2458,7 +2556,18 @@ restart:
     io.delim = delim;
     bool full = false;
     __syncthreads();
-    if (!fused || m > n / 16u) {
+    if (narrow && m > n / 16u) {
+        // many suffixes still tied (text): the rounds to come read rank[] of any suffix.  The fused
+        // rerank has written them all when every bucket held many tied suffixes; else the missing ones
+        // are looked up.  (Nearly) every suffix with a twin is repeated text, which the common-case
+        // kernel leaves to the other one.
+        if (!HEAVY && n >= kPeriodicMinBlock && m >= n - 64u) {  // workgroup-uniform
+            put_off();
+            return;
+        }
+        if (ranks_skipped && !periodic) fill_unique_ranks<NT>(fx, r0, sh.sym, rank);
+        full = true;
+    } else if (!fused || m > n / 16u) {
         // (nearly) every suffix with a twin after round 0 is repeated text: the common-case kernel
         // learns that from the count and leaves the block to the other one before the costly sweep
         const uint32_t bail_at = !HEAVY && n >= kPeriodicMinBlock ? n - 64u : 0xFFFFFFFFu;
@@ -2493,7 +2602,9 @@ restart:
         const bool any = __ballot(valid && tied) != 0ull;  // without ties the ranks are exact already
         if (any) {
             uint32_t rk[1];
-            ranks_by_search<1>(sorted0, r0, sh.sym, jt, rk);
+            bool alone[1];
+            if (narrow) ranks_by_fine_search<1>(fx, r0, sh.sym, jt, rk, alone);
+            else ranks_by_search<1>(sorted0, r0, sh.sym, jt, rk);
             if (valid) sh.tailrow[lane] = rk[0] + ahead;
         }
         if (lane == 0) sh.tailrow[kMaxM0] = any ? 1u : 0u;
@@ -2594,7 +2705,9 @@ restart:
                         j[u] = (uint32_t)(e[u] & imask) + h;
                     }
                     uint32_t rk[U];
-                    ranks_by_search<U>(sorted0, r0, sh.sym, j, rk);
+                    bool alone[U];
+                    if (narrow) ranks_by_fine_search<U>(fx, r0, sh.sym, j, rk, alone);
+                    else ranks_by_search<U>(sorted0, r0, sh.sym, j, rk);
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const uint32_t k = base + (uint32_t)(u * kWave + lane);
@@ -2641,13 +2754,30 @@ restart:
         pc.count(9, 1);
         if (!full) {
             if (m2 == 0) break;
-            // survivors remain after the searched round: build the complete rank array from the
-            // round-0 order and redo this round with it (rare: long repeats in otherwise easy data)
-            rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, true, 0xFFFFFFFFu, sh, m, G, full);
-            cur = sorted0;
-            alt = spare;
-            pc.lap(7);
-            continue;
+            // survivors remain after the searched round (rare: long repeats in otherwise easy data):
+            // the rounds to come read rank[] of any suffix
+            if (narrow) {
+                // the tied suffixes have their ranks of this round; the others get their rows looked up,
+                // and the doubling goes on with the list at hand in the halves of `spare`
+                fill_unique_ranks<NT>(fx, r0, sh.sym, rank);
+                full = true;
+                // from here on both sides of the ping-pong are whole buffers again (later steps use the
+                // scratch side for tables of n + 1 words): the list moves to the start of `spare`
+                if (other != spare) {
+                    for (uint32_t i = tid; i < m2; i += NT) spare[i] = other[i];
+                    __syncthreads();
+                    other = spare;
+                }
+                sorted = sorted0;
+                pc.lap(7);
+            } else {
+                // build the complete rank array from the round-0 order and redo this round with it
+                rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, true, 0xFFFFFFFFu, sh, m, G, full);
+                cur = sorted0;
+                alt = spare;
+                pc.lap(7);
+                continue;
+            }
         }
         cur = sorted;
         alt = other;
