@@ -35,6 +35,8 @@
 // buffers, one u32 rank array, a small bucket directory); LDS holds the staging tiles, the
 // bucket being sorted and the counters.
 #pragma once
+#include <type_traits>
+
 #include "bwt_device.hpp"
 
 namespace bwtgpu {
@@ -708,31 +710,52 @@ __device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit&
             prevw[0] = __builtin_amdgcn_alignbyte(pw[1], pw[0], pmis);
             prevw[1] = __builtin_amdgcn_alignbyte(pw[2], pw[1], pmis);
         }
-        uint64_t key = 0;
         uint64_t el[kRun];
         uint32_t valid_bits = 0;
+        // The steps come in four variants: keys of at most 32 bits (ACGT: 24, four bytes of an
+        // alphabet of up to 256 symbols: 32) roll in one register with a shift-or and an and per
+        // symbol; and a tile whose windows end before the text does, and that is not the block's
+        // first, needs none of the checks for the delimiter, the end and suffix 0: all its
+        // positions are main suffixes of the wave's chunk.
+        auto steps = [&](auto edge_tag, auto key0) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            using KT = decltype(key0);
+            KT key = 0;
+            const KT kmask = (KT)r.kmask;
 #pragma unroll
-        for (int t = 0; t < 16 + kRun; ++t) {
-            if (t >= lead) {  // wave-uniform
-                const uint32_t pos = q0 + (uint32_t)(t - lead);  // = wstart + t, never negative here
-                const uint32_t byte = (win[t >> 2] >> (8 * (t & 3))) & 255u;
-                uint32_t c = (uint32_t)sh.sym[byte];
-                if (pos >= r.len) c = (pos == r.len) ? r.dcode : r.pad;
-                key = ((key << r.sbits) | c) & r.kmask;
-            }
-            if (t >= 16) {
-                const int j = t - 16;
-                const uint32_t pe = q0 + (uint32_t)j;
-                const bool valid = pe < hi;
-                if (MODE == 0) {  // main suffixes only (short window); the tails are counted by count_tails
-                    if (valid && pe < r.nm) atomicAdd(&sh.u.fine[(uint32_t)((2ull * key + 1ull) >> r.fshift)], 1u);
-                } else {
-                    uint32_t prev = (prevw[j >> 2] >> (8 * (j & 3))) & 255u;
-                    if (pe == 0) prev = r.delim;  // the row of suffix 0 carries the delimiter (src/bwt.cpp:115-116)
-                    el[j] = (round0_key(r, key, pe) << kshift) | ((uint64_t)prev << r.ibits) | pe;
-                    if (valid) valid_bits |= 1u << j;
+            for (int t = 0; t < 16 + kRun; ++t) {
+                if (t >= lead) {  // wave-uniform
+                    const uint32_t byte = (win[t >> 2] >> (8 * (t & 3))) & 255u;
+                    uint32_t c = (uint32_t)sh.sym[byte];
+                    if (EDGE) {
+                        const uint32_t pos = q0 + (uint32_t)(t - lead);  // = wstart + t, never negative here
+                        if (pos >= r.len) c = (pos == r.len) ? r.dcode : r.pad;
+                    }
+                    key = ((key << r.sbits) | (KT)c) & kmask;
+                }
+                if (t >= 16) {
+                    const int j = t - 16;
+                    const uint32_t pe = q0 + (uint32_t)j;
+                    const bool valid = !EDGE || pe < hi;
+                    if (MODE == 0) {  // main suffixes only (short window); the tails are counted by count_tails
+                        if (valid && (!EDGE || pe < r.nm)) atomicAdd(&sh.u.fine[(uint32_t)((2ull * (uint64_t)key + 1ull) >> r.fshift)], 1u);
+                    } else {
+                        uint32_t prev = (prevw[j >> 2] >> (8 * (j & 3))) & 255u;
+                        if (EDGE && pe == 0) prev = r.delim;  // the row of suffix 0 carries the delimiter (src/bwt.cpp:115-116)
+                        const uint64_t k0 = EDGE ? round0_key(r, (uint64_t)key, pe) : 2ull * (uint64_t)key + 1ull;
+                        el[j] = (k0 << kshift) | ((uint64_t)prev << r.ibits) | pe;
+                        if (valid) valid_bits |= 1u << j;
+                    }
                 }
             }
+        };
+        const bool edge = tile == 0u || tile + (uint32_t)kTile + 24u > r.len;  // wave-uniform
+        if (r.kmask <= 0xFFFFFFFFull) {
+            if (edge) steps(std::true_type{}, (uint32_t)0);
+            else steps(std::false_type{}, (uint32_t)0);
+        } else {
+            if (edge) steps(std::true_type{}, (uint64_t)0);
+            else steps(std::false_type{}, (uint64_t)0);
         }
         if (MODE == 1) {
             // The partition needs no particular order inside a bucket: every element takes its

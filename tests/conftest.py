@@ -14,6 +14,15 @@ CORPUS = os.path.join(ROOT, "data", "canterbury_corpus")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # PyTorch ships its own HIP runtime; it finds no device when the system runtime that
+    # libbwtgpu.so links has been initialised first in the same process.  Let torch look first,
+    # whatever subset of the tests is run.
+    try:
+        import torch
+
+        torch.cuda.is_available()
+    except Exception:
+        pass
 
 
 def load_golden(name):
