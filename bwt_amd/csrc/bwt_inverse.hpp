@@ -771,21 +771,20 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
 
 // Moves every chained segment from its staging slot (and pool chunks) to its place: the bytes
 // were produced back to front, so byte t of the segment lands t + 1 bytes below its upper end.
-// Lane k takes the k-th segment ON THE CHAIN (seg_rec), not segment k: neighbouring lanes then
-// write neighbouring stretches of the text, which the L2 merges into whole lines (with lane =
-// segment id every lane wrote its 16 bytes or so to a place of its own, and the pass wrote 2.8
-// times its payload to HBM); what stays random is the read of the segment's staging line.
-__global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
-    uint32_t b, k;
-    if (!segment_of_lane(a, b, k)) return;
-    const uint32_t n = inv_block_len(a, b);
-    const uint64_t sb = (uint64_t)b * a.seg_cap;
-    const uint2 whole = a.chain[b];
-    if (k >= whole.x || k >= a.seg_cap) return;  // segments off the chain (a cycle the delimiter's chain never reaches) have no place
-    const uint2 rec = a.seg_rec[sb + k];
-    const uint32_t j = rec.x, pos = rec.y;
-    const uint32_t len = (k + 1u < whole.x ? a.seg_rec[sb + k + 1u].y : whole.y) - pos;
-    if ((uint64_t)pos + len > (uint64_t)(n - 1)) return;  // never: the chain is at most n-1 bytes long
+// Lane k takes the k-th segment ON THE CHAIN (seg_rec), not segment k, so the 256 lanes of a
+// workgroup own one contiguous stretch of the text (about 4 KiB).
+//
+// place_segment_direct writes a segment straight to the text: an unaligned source dword (funnel
+// shift) byte-swapped is an aligned destination dword; 16-byte stores where aligned, dword / byte
+// stores at the ragged ends.  With every lane doing that, the pieces of a 64-byte line arrive from
+// different lanes at different times and the pass wrote 2.6 times its payload to HBM.  So the
+// workgroup first assembles its stretch in LDS (in walk order, which is the text reversed: a
+// plain copy of every segment to its offset) and then writes it out as whole aligned 16-byte
+// groups, each group byte-reversed; only the stretch's two ragged ends go byte by byte, and
+// segments that reach beyond the LDS window (kPlaceWindow bytes: four times the average stretch)
+// are written directly as before.
+__device__ __forceinline__ void place_segment_direct(const InvArgs& a, uint32_t b, uint32_t j, uint32_t pos,
+                                                     uint32_t len, uint32_t n, uint64_t sb) {
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
     const uint8_t* src = a.stage + (sb + j) * a.slot;
     uint32_t c = 0;
@@ -829,6 +828,109 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
         prev = v.w;
     }
     bw.flush();
+}
+
+constexpr uint32_t kPlaceWindow = 16384;  // bytes of a workgroup's stretch that are assembled in LDS
+
+__global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
+    __shared__ uint32_t s_buf[kPlaceWindow / 4 + 8];  // walk order; 16 bytes of slack for the alignment shift
+    __shared__ uint32_t s_p0, s_cut, s_end;
+    uint32_t b, k;
+    if (!segment_of_lane(a, b, k)) return;  // workgroup-uniform: all lanes of a workgroup serve one block
+    const uint32_t n = inv_block_len(a, b);
+    const uint64_t sb = (uint64_t)b * a.seg_cap;
+    const uint2 whole = a.chain[b];
+    const uint32_t k0 = k - threadIdx.x;  // the workgroup's first segment on the chain
+    if (k0 >= whole.x || k0 >= a.seg_cap) return;  // workgroup-uniform: segments off the chain have no place
+    const bool mine = k < whole.x && k < a.seg_cap;
+    uint32_t j = 0, pos = 0, len = 0;
+    if (mine) {
+        const uint2 rec = a.seg_rec[sb + k];
+        j = rec.x;
+        pos = rec.y;
+        len = (k + 1u < whole.x ? a.seg_rec[sb + k + 1u].y : whole.y) - pos;
+        if ((uint64_t)pos + len > (uint64_t)(n - 1)) len = 0;  // never: the chain is at most n-1 bytes long
+    }
+    if (threadIdx.x == 0) {
+        s_p0 = pos;
+        s_cut = 0xFFFFFFFFu;
+        s_end = 0;
+    }
+    __syncthreads();
+    const uint32_t p0 = s_p0;  // walk-order offset of the stretch's first byte (its LAST byte in the text)
+    // Walk-order offset o (from p0) <-> text address top - o, top = address of the stretch's last text byte.
+    uint8_t* const top = a.out + (uint64_t)b * a.out_stride + (n - 2u) - p0;
+    const uint32_t shift = (uint32_t)((16u - ((uint32_t)reinterpret_cast<uintptr_t>(top + 1) & 15u)) & 15u);  // LDS index = o + shift
+    uint8_t* const eup = top + 1 + shift;  // 16-byte aligned: LDS index i <-> address eup - 1 - i
+    const bool far = mine && (pos - p0) + len > kPlaceWindow;  // reaches beyond the window: written directly
+    if (far) atomicMin(&s_cut, pos - p0);
+    else if (len) atomicMax(&s_end, pos - p0 + len);
+    __syncthreads();
+    const uint32_t span = min(s_cut, s_end);  // walk-order bytes [0, span) of the stretch go through LDS
+    if (far) {
+        place_segment_direct(a, b, j, pos, len, n, sb);
+    } else if (len) {
+        // plain copy of the staged bytes to LDS index pos - p0 + shift ..: bytes up to the first dword
+        // boundary, whole dwords (funnel shift over the aligned source), bytes at the end
+        uint8_t* const lb = reinterpret_cast<uint8_t*>(s_buf);
+        const uint32_t d0 = pos - p0 + shift;
+        const uint32_t head = min(len, (4u - (d0 & 3u)) & 3u);
+        const uint32_t nd = (len - head) >> 2, tail = len - head - 4u * nd;
+        const uint64_t pb = (uint64_t)b * a.chunk_cap;
+        const uint8_t* src = a.stage + (sb + j) * a.slot;
+        uint32_t c = 0, prev = 0;
+        const uint32_t last_group = (nd + 1u) >> 2;      // source dwords 0 .. nd+1 are consulted
+        uint32_t* const ld = s_buf + ((d0 + head) >> 2);
+        for (uint32_t g = 0; g <= last_group; ++g) {
+            if (g && (g & ((a.slot / 16u) - 1u)) == 0u && 16u * g < len) {  // the next chunk of a long segment
+                c = g == (a.slot / 16u) ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
+                if (c >= a.chunk_cap) break;  // never
+                src = a.pool + (pb + c) * a.slot;
+            }
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + ((16u * g) & (a.slot - 1u)));
+            if (g == 0) {
+                for (uint32_t t = 0; t < head; ++t) lb[d0 + t] = (uint8_t)(v.x >> (8u * t));
+            }
+            const uint32_t lo[4] = {prev, v.x, v.y, v.z}, hi[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t d = 4u * g + (uint32_t)q - 1u;  // destination dword this pair yields (g = 0, q = 0: none)
+                if (d <= nd && !(g == 0 && q == 0)) {
+                    uint32_t w = lo[q];  // source bytes head + 4 d ..
+                    if (head == 1) w = __builtin_amdgcn_alignbyte(hi[q], lo[q], 1);
+                    else if (head == 2) w = __builtin_amdgcn_alignbyte(hi[q], lo[q], 2);
+                    else if (head == 3) w = __builtin_amdgcn_alignbyte(hi[q], lo[q], 3);
+                    if (d < nd) {
+                        ld[d] = w;
+                    } else {
+                        for (uint32_t t = 0; t < tail; ++t) lb[d0 + head + 4u * nd + t] = (uint8_t)(w >> (8u * t));
+                    }
+                }
+            }
+            prev = v.w;
+        }
+    }
+    __syncthreads();
+    // write the stretch out: LDS indices [shift, shift + span) <-> addresses eup - 1 - i.  Group c = indices
+    // 16 c .. 16 c + 15 is one aligned 16-byte store, its bytes reversed.
+    if (span == 0u) return;
+    const uint32_t lo_i = shift, hi_i = shift + span;  // valid LDS indices
+    const uint32_t groups = (hi_i + 15u) >> 4;
+    const uint8_t* const lb = reinterpret_cast<const uint8_t*>(s_buf);
+    for (uint32_t c = threadIdx.x; c < groups; c += kSegThreads) {
+        uint8_t* const dst = eup - 16u * (c + 1u);
+        if (16u * c >= lo_i && 16u * c + 16u <= hi_i) {
+            const uint4 v = *reinterpret_cast<const uint4*>(s_buf + 4u * c);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z),
+                                                        __builtin_bswap32(v.y), __builtin_bswap32(v.x));
+        } else {
+            for (uint32_t t = 0; t < 16u; ++t) {
+                const uint32_t i = 16u * c + t;
+                if (i >= lo_i && i < hi_i) dst[15u - t] = lb[i];
+            }
+        }
+    }
 }
 
 // ---- origin-pointer blocks: the last step --------------------------------------------------------

@@ -4,7 +4,7 @@
 args=$1; shift
 for v in "$@"; do
   lib=$PWD/build/x/lib_$v.so; [ "$v" = base ] && lib=$PWD/bwt_amd/libbwtgpu.so
-  BWTGPU_LIB=$lib BWTGPU_PHASES=${PHASES:-second} timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-workloads $args > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
+  BWTGPU_LIB=$lib BWTGPU_PHASES=${PHASES:-second} timeout -k 10 300 python bench.py --no-cpu-baseline --no-e2e --no-other-workloads $args > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
   python3 - $v <<'PY'
 import json, sys
 v = sys.argv[1]

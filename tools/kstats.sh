@@ -4,8 +4,8 @@ tag=$1; shift
 out=gpurun_out/ks_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads "$@" > $out.log 2>&1 || { echo failed; tail -5 $out.log; exit 1; }
-f=$(find $out -name '*kernel_stats.csv' | head -1)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-workloads "$@" > $out.log 2>&1 || { echo failed; tail -5 $out.log; exit 1; }
+f=$(ls -S $(find $out -name '*kernel_stats.csv') | head -1)  # the largest: the bench process itself, not a child
 cp $f $out.csv
 python3 - $out.csv $out.log <<'PY'
 import csv, json, sys

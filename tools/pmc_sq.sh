@@ -3,7 +3,7 @@
 # usage: tools/pmc_sq.sh [tag] [extra bench args...]
 tag=${1:-sq}; shift
 mkdir -p gpurun_out
-B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads $@"
+B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-other-workloads $@"
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS -d gpurun_out/pmc_${tag}_a --output-format csv -- $B > gpurun_out/pmc_${tag}_a.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA -d gpurun_out/pmc_${tag}_b --output-format csv -- $B > gpurun_out/pmc_${tag}_b.log 2>&1 || exit 1
 python - <<PY

@@ -4,15 +4,15 @@ tag=$1; shift
 out=gpurun_out/pt_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads"
+B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-other-workloads"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch --output-format csv -- $B "$@" > $out/fetch.log 2>&1 || { echo fetch failed; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write --output-format csv -- $B "$@" > $out/write.log 2>&1 || { echo write failed; exit 1; }
 python3 - $out <<'PY'
-import csv, glob, json, collections, sys
+import csv, glob, json, collections, os, sys
 out = sys.argv[1]
 res = collections.defaultdict(dict)
 for name in ("fetch", "write"):
-    f = glob.glob(out + "/%s/**/*counter_collection.csv" % name, recursive=True)[0]
+    f = max(glob.glob(out + "/%s/**/*counter_collection.csv" % name, recursive=True), key=os.path.getsize)
     acc = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         if "bwtgpu" in r["Kernel_Name"]:

@@ -7,19 +7,19 @@ wl=${2:-acgt-4g-256k}
 out=gpurun_out/prof_${tag}_$wl
 mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --workload $wl"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-other-workloads --workload $wl"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- $B > $out/stats.log 2>&1 || { echo stats failed; tail -5 $out/stats.log; exit 1; }
-B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-workloads --workload $wl"
+B1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-other-workloads --workload $wl"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch --output-format csv -- $B1 > $out/fetch.log 2>&1 || { echo fetch failed; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write --output-format csv -- $B1 > $out/write.log 2>&1 || { echo write failed; exit 1; }
 python - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, os
 out = "$out"
-stats = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]
+stats = max(glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True), key=os.path.getsize)
 open(out + "/kernel_stats.csv", "w").write(open(stats).read())
 res = collections.defaultdict(dict)
 for name in ("fetch", "write"):
-    f = glob.glob(out + "/%s/**/*counter_collection.csv" % name, recursive=True)[0]
+    f = max(glob.glob(out + "/%s/**/*counter_collection.csv" % name, recursive=True), key=os.path.getsize)
     acc = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         if "bwtgpu" in r["Kernel_Name"]:
