@@ -45,6 +45,21 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The same with a digit width known only at run time (wave-uniform): one ballot per bit that
+// any digit can have set.
+__device__ __forceinline__ uint64_t match_digit_bits(uint32_t d, bool valid, int bits) {
+    const uint64_t vm = __ballot(valid);
+    uint32_t lo = (uint32_t)vm, hi = (uint32_t)(vm >> 32);
+#pragma unroll 1
+    for (int b = 0; b < bits; ++b) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+        const uint64_t bal = __ballot(x != 0u);
+        lo &= ~((uint32_t)bal ^ x);
+        hi &= ~((uint32_t)(bal >> 32) ^ x);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // Keeps the compiler from moving memory operations across this point (used where lanes of
 // one wave hand values to each other through LDS and the order of a read and a later write
 // matters).

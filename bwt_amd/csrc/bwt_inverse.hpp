@@ -131,6 +131,8 @@ struct InvShared {
     uint32_t drow[W];
     uint32_t ndelim;
     uint32_t blk;
+    uint32_t sigma;       // distinct byte values in the block
+    uint8_t code[256];    // byte value -> its index among the values that occur (ranking compares codes: fewer bits, fewer ballots)
 };
 
 __device__ __forceinline__ uint32_t inv_block_len(const InvArgs& a, uint32_t b) {
@@ -227,8 +229,14 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
                     sh.hist[i * 256 + tid] = run;
                     run += v;
                 }
+            // dense codes of the byte values that occur
+            uint32_t sigma;
+            const uint32_t below = block_exclusive_scan<NT>(tid < 256 && tot ? 1u : 0u, sh.wsum, sigma);
+            if (tid < 256) sh.code[tid] = (uint8_t)below;
+            if (tid == 0) sh.sigma = sigma;
         }
         __syncthreads();
+        const int cbits = max(1, bit_length(sh.sigma - 1u));
         uint32_t drow = kNoRow;  // rows grow with the wave index, so the last hit wins
 #pragma unroll
         for (int i = 0; i < W; ++i)
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
                     const uint32_t k = base + lane;
                     const bool valid = k < hi;
                     const uint32_t c = cs[u];
-                    const uint64_t peers = match_digit<8>(c, valid);
+                    const uint64_t peers = match_digit_bits((uint32_t)sh.code[c], valid, cbits);
                     const uint32_t rk = __popcll(peers & lt);
                     const uint32_t b0 = myoff[c];
                     compiler_fence();  // every lane has read its offset before the leaders advance it
@@ -366,6 +374,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, I
         uint32_t total;
         const uint32_t c0 = block_exclusive_scan<NT>(all, sh.wsum, total);
         if (tid < 256) s_base[tid] = c0 + before;
+        uint32_t sigma;  // dense codes of the byte values that occur in the block, as in bwt_inverse_build_kernel
+        const uint32_t below = block_exclusive_scan<NT>(tid < 256 && all ? 1u : 0u, sh.wsum, sigma);
+        if (tid < 256) sh.code[tid] = (uint8_t)below;
+        if (tid == 0) sh.sigma = sigma;
     }
     const uint32_t dlast = ta.dacc[2u * b], ndelim = ta.dacc[2u * b + 1u];
     uint32_t drow = dlast ? dlast - 1u : kNoRow;
@@ -381,6 +393,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, I
     }
     const bool split = mode == kModeMulti;
     __syncthreads();
+    const int cbits = max(1, bit_length(sh.sigma - 1u));
     Chunking ck;
     ck.init(thi - tlo, W);
     const uint32_t lo = min(tlo + (uint32_t)w * ck.chunk, thi), hi = min(lo + ck.chunk, thi);
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_tile_build_kernel(InvArgs a, I
                 const uint32_t k = base + lane;
                 const bool valid = k < hi;
                 const uint32_t c = cs[u];
-                const uint64_t peers = match_digit<8>(c, valid);
+                const uint64_t peers = match_digit_bits((uint32_t)sh.code[c], valid, cbits);
                 const uint32_t rk = __popcll(peers & lt);
                 const uint32_t b0 = myoff[c];
                 compiler_fence();  // every lane has read its offset before the leaders advance it
@@ -545,19 +558,25 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
 // differently only the cache locality would suffer.)
 // Segment j < regular_splitters(n) starts at the row whose image is j, j == regular_splitters(n)
 // starts at the delimiter row.  (A regular splitter that IS the delimiter row is left to the latter.)
+template <int NT = kSegThreads>
 __device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, uint32_t& j) {
+    const uint32_t wgs = (a.seg_cap + (uint32_t)NT - 1u) / (uint32_t)NT;  // workgroups that cover one block's segments
     const uint32_t w = blockIdx.x, x = w & 7u, q = w >> 3;
-    b = (q / a.seg_wgs) * 8u + x;
-    j = (q % a.seg_wgs) * (uint32_t)kSegThreads + threadIdx.x;
+    b = (q / wgs) * 8u + x;
+    j = (q % wgs) * (uint32_t)NT + threadIdx.x;
     return b < a.nblocks && a.mode[b] == kModeMulti;
 }
+// The walk runs in workgroups of a single wave: a workgroup's slot on its compute unit is taken until
+// its LONGEST segment is done (segment lengths are geometric, mean 16: the longest of 64 is about 76
+// steps, of 256 about 98), and a slot that is given back earlier starts the next wave earlier.
+constexpr int kWalkThreads = kWave;
 
 // Walks every segment once: its length, the splitter it runs into, and its bytes -- in walk
 // order, 16 at a time -- into the segment's staging slot (then chained pool chunks).
 template <typename TW>
-__global__ __launch_bounds__(kSegThreads) void bwt_inverse_walk_segments_kernel(InvArgs a) {
+__global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel(InvArgs a) {
     uint32_t b, j;
-    if (!segment_of_lane(a, b, j)) return;
+    if (!segment_of_lane<kWalkThreads>(a, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
     const uint32_t nreg = regular_splitters(n, a.split_shift);
     if (j > nreg) return;

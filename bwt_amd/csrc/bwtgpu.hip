@@ -909,8 +909,10 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
     if (g.split) {
         const uint64_t wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * g.seg_wgs;
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
-        if (g.wide) hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint64_t>, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
-        else hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint32_t>, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
+        const uint64_t walk_wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * ((g.seg_cap + kWalkThreads - 1) / kWalkThreads);
+        if (walk_wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
+        if (g.wide) hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint64_t>, dim3((uint32_t)walk_wgs), dim3(kWalkThreads), 0, s, a);
+        else hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint32_t>, dim3((uint32_t)walk_wgs), dim3(kWalkThreads), 0, s, a);
         HIP_TRY(hipGetLastError());
         // many segments per block, or few blocks (the chain following is then the whole cost): the
         // records go through LDS
