@@ -1093,10 +1093,24 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
     uint32_t cA = 0, cG = 0, lH = 0;
     constexpr int U = 4;  // vectors whose LDS reads are issued together (the loop is latency bound otherwise)
     const uint32_t kmax = cnt - 1u;
+    const bool narrow = fshift >= 0;
+    const uint32_t fmask = narrow ? (uint32_t)((1ull << fshift) - 1ull) : 0u;
+    // The usual bucket (narrow mode, few suffixes stay tied) is done in this one sweep: everything that
+    // does not depend on the other waves' counts is written at once, and the few tied suffixes wait
+    // in LDS (two words each: position; run head inside the bucket, or kCarry when the run began in an
+    // earlier wave's share, and group number inside the wave's share + 1) until the counts are known.
+    constexpr uint32_t kFlagWords = (uint32_t)W * 2u * (uint32_t)kVecsPerWave * 2u;
+    constexpr uint32_t kStageCap = ((uint32_t)(sizeof(sh.v.cw) / sizeof(uint32_t)) - kFlagWords) / (uint32_t)W / 2u;
+    constexpr uint32_t kCarry = 0xFFFFu;
+    static_assert(kStageCap >= 64 && FwdShared<NT>::kSortCap < (int)kCarry, "room for some tied suffixes per wave; run heads fit 16 bits");
+    uint32_t* const stage = sh.v.cw + kFlagWords + (uint32_t)w * kStageCap * 2u;
+    const bool fast = narrow && !all_ranks;
+    uint32_t nst = 0;
+    bool seen_head = false;  // a run head in my share so far (wave-uniform)
     {
         uint32_t v = 0;
         for (uint32_t base = lo; base < hi; base += U * kWave, v += U) {
-            uint64_t key[U], kp[U], kn[U];
+            uint64_t key[U], kp[U], kn[U], y[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {  // clamped indices: every read is in range, the flags below sort out validity
                 const uint32_t k = base + (uint32_t)(u * kWave + lane);
@@ -1104,11 +1118,17 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
                 if (ks >= 32) {  // the key fits the high dword: 4-byte LDS reads
                     const uint32_t* hi32 = reinterpret_cast<const uint32_t*>(ls) + 1;
                     const int sh32 = ks - 32;
-                    key[u] = hi32[2 * kc] >> sh32;
+                    if (fast) {
+                        y[u] = ls[kc];
+                        key[u] = (uint32_t)(y[u] >> 32) >> sh32;
+                    } else {
+                        key[u] = hi32[2 * kc] >> sh32;
+                    }
                     kp[u] = hi32[2 * kl] >> sh32;
                     kn[u] = hi32[2 * kr] >> sh32;
                 } else {
-                    key[u] = ls[kc] >> ks;
+                    y[u] = ls[kc];
+                    key[u] = y[u] >> ks;
                     kp[u] = ls[kl] >> ks;
                     kn[u] = ls[kr] >> ks;
                 }
@@ -1126,9 +1146,28 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
                         flags[2 * (v + u)] = H;
                         flags[2 * (v + u) + 1] = T;
                     }
-                    cA += __popcll(__ballot(valid) & ~(H & T));
-                    cG += __popcll(H & ~T);
-                    if (H) lH = vb + 63u - (uint32_t)__clzll(H);
+                    const uint64_t A = __ballot(valid) & ~(H & T), NS = H & ~T;
+                    if (fast) {
+                        const uint64_t ec = (y[u] >> up) + bsub;
+                        if (valid) nk[s0 + k] = (uint32_t)(ec >> kshift) & fmask;
+                        if (head && tail) out[s0 + k] = (uint8_t)(ec >> ibits);
+                        if (valid && !(head && tail)) {
+                            const uint64_t hm = H & le;
+                            const uint32_t kh = hm ? vb + 63u - (uint32_t)__clzll(hm) : seen_head ? lH : kCarry;
+                            const uint32_t li = nst + (uint32_t)__popcll(A & lt);
+                            if (li < kStageCap) {
+                                stage[2u * li] = (uint32_t)(ec & imask);
+                                stage[2u * li + 1u] = kh | ((cG + (uint32_t)__popcll(NS & le)) << 16);
+                            }
+                        }
+                        nst += (uint32_t)__popcll(A);
+                    }
+                    cA += __popcll(A);
+                    cG += __popcll(NS);
+                    if (H) {
+                        lH = vb + 63u - (uint32_t)__clzll(H);
+                        seen_head = true;
+                    }
                 }
             }
         }
@@ -1137,6 +1176,7 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
         sh.cntA[w] = cA;
         sh.cntG[w] = cG;
         sh.lastH[w] = lH;
+        sh.lastG[w] = nst > kStageCap ? 1u : 0u;
     }
     __syncthreads();
     uint32_t baseA = m_tot, baseG = g_tot, carryH = 0, totA = 0, totG = 0;
@@ -1151,13 +1191,21 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
         totA += ca;
         totG += cg;
     }
-    const bool narrow = fshift >= 0;
-    const uint32_t fmask = narrow ? (uint32_t)((1ull << fshift) - 1ull) : 0u;
     if (narrow && !all_ranks) {
         all_ranks = totA * 16u > cnt;  // workgroup-uniform
         if (!all_ranks) skipped = true;
     }
-    {
+    bool staged = fast && !all_ranks;  // the tied suffixes of every wave are waiting in LDS
+#pragma unroll
+    for (int i = 0; i < W; ++i) staged = staged && sh.lastG[i] == 0u;
+    if (staged) {
+        for (uint32_t i = (uint32_t)lane; i < nst; i += kWave) {
+            const uint32_t idx = stage[2u * i], w1 = stage[2u * i + 1u];
+            const uint32_t kh = (w1 & 0xFFFFu) == kCarry ? carryH : (w1 & 0xFFFFu);
+            rank[idx] = s0 + kh;
+            nxt[baseA + i] = ((uint64_t)(baseG + (w1 >> 16) - 1u) << gshift) | idx;
+        }
+    } else {
         uint32_t v = 0;
         for (uint32_t base0 = lo; base0 < hi; base0 += U * kWave, v += U) {
             uint64_t y[U], Hs[U], Ts[U];
