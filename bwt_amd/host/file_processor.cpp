@@ -15,13 +15,21 @@ namespace {
 // that pread / pwrite disjoint ranges.
 constexpr size_t kParallelMin = (size_t)8 << 20;   // below this one call is as fast
 constexpr size_t kBytesPerThread = (size_t)4 << 20;
-constexpr size_t kMaxIoThreads = 8;
+// threads a bulk read or write is split over: BWT_IO_THREADS, default 8
+size_t max_io_threads() {
+    static const size_t n = [] {
+        const char* e = std::getenv("BWT_IO_THREADS");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v > 0 && v <= 64 ? v : 8);
+    }();
+    return n;
+}
 
 // Runs op(offset, length) -> bytes done over [0, n) in parallel; returns the length of the
 // prefix that was fully transferred.
 template <typename Op>
 size_t parallel_ranges(size_t n, Op op) {
-    const size_t nt = std::max<size_t>(1, std::min(kMaxIoThreads, n / kBytesPerThread));
+    const size_t nt = std::max<size_t>(1, std::min(max_io_threads(), n / kBytesPerThread));
     const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
     std::vector<size_t> done(nt, 0);
     std::vector<std::thread> threads;
@@ -120,7 +128,7 @@ std::string FileProcessor::read_chunk() {
 bool FileProcessor::read_char(char& c) { return read_bytes(&c, 1) == 1; }
 
 bool FileProcessor::write_bytes(const char* src, size_t n) {
-    std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::mutex> lock(out_mutex_);
     if (!out_ || n == 0) return true;
     if (out_regular_ && n >= kParallelMin && std::fflush(out_) == 0) {
         const off_t pos = ::ftello(out_);
@@ -146,6 +154,7 @@ void FileProcessor::write_chunk(const std::string& chunk) { (void)write_bytes(ch
 
 void FileProcessor::close() {
     std::lock_guard<std::mutex> lock(mutex_);
+    std::lock_guard<std::mutex> out_lock(out_mutex_);
     if (in_) {
         std::fclose(in_);
         in_ = nullptr;

@@ -53,7 +53,11 @@ private:
     bool regular_ = false;
     bool out_regular_ = false;
     std::vector<char> scratch_;
-    mutable std::mutex mutex_;  // one lock for both streams, as in the reference
+    // The reference guards both streams with one lock (src/file_processor.hpp:45); here each stream has
+    // its own, so that the thread that reads slabs and the thread that writes results do not wait for
+    // each other.  Every method is still safe to call from any thread.
+    mutable std::mutex mutex_;      // input stream
+    mutable std::mutex out_mutex_;  // output stream
 };
 
 #endif  // FILE_PROCESSOR_HPP

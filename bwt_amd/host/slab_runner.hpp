@@ -1,21 +1,30 @@
 // slab_runner.hpp -- drives the C ABI's slab pipelines over a file, in order.
 //
 // This is what stands where the reference has its reader thread, BlockingQueue, worker
-// pool, ReorderBuffer and writer thread (reference src/bwt.cpp:183-233): the calling thread
-// reads whole slabs of blocks into pinned memory and submits them round-robin to one
-// pipeline per GPU; each slot's upload, kernels and download run on its own HIP stream,
-// and results are written back in submission order, so the file order is kept without a
-// reorder buffer.  Blocks never interact, so how they are cut into slabs, and which GPU
-// gets which slab, cannot change a single output byte.
+// pool, ReorderBuffer and writer thread (reference src/bwt.cpp:183-233): whole slabs of blocks
+// are read into pinned memory and submitted round-robin to one pipeline per GPU; each slot's
+// upload, kernels and download run on its own HIP stream, and results are written back in
+// submission order, so the file order is kept without a reorder buffer.  Blocks never interact,
+// so how they are cut into slabs, and which GPU gets which slab, cannot change a single output
+// byte.
+// A file of one slab is driven by the calling thread alone (run_slabs_serial: thread start-up
+// would cost more than the transform).  Longer inputs get the reference's three roles back as
+// threads (run_slabs_threaded): the calling thread reads, ONE thread per GPU submits that GPU's
+// slabs (a submit that has to wait for the device -- the device-wide path for few large blocks
+// reads intermediate counts back -- then holds up that GPU only), and one thread collects the
+// results in file order and writes them, which is what frees a slot for the reader.
 #ifndef SLAB_RUNNER_HPP
 #define SLAB_RUNNER_HPP
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <iostream>
 #include <mutex>
+#include <thread>
+#include <string>
 #include <vector>
 
 #include "bwtgpu.h"
@@ -126,8 +135,8 @@ private:
 
 // Streams `processor`'s remaining input through the transform and writes the results.
 // unit = bytes one block occupies in the INPUT (block_size forward, block_size+1 inverse).
-inline int run_slabs(FileProcessor& processor, int direction, size_t block_size, unsigned char delimiter,
-                     size_t remaining_bytes) {
+inline int run_slabs_serial(FileProcessor& processor, int direction, size_t block_size, unsigned char delimiter,
+                            size_t remaining_bytes) {
     if (processor.input_is_regular() && remaining_bytes == 0) return 0;  // nothing after the header
     const int ndev = device_budget();
     if (ndev <= 0) {
@@ -210,6 +219,151 @@ inline int run_slabs(FileProcessor& processor, int direction, size_t block_size,
         else PipelineCache::instance().release(leases[d], (int)d, direction, block_size, depth);
     }
     return rc;
+}
+
+
+// The same with a reader (the calling thread), one submitting thread per GPU and a writer.
+// Slab k goes to GPU k % G, slot (k / G) % depth; a slot is Free -> Filled (read) -> Submitted ->
+// Free again (collected and written).
+inline int run_slabs_threaded(FileProcessor& processor, int direction, size_t block_size, unsigned char delimiter,
+                              size_t remaining_bytes) {
+    const int ndev = device_budget();
+    if (ndev <= 0) {
+        std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+        return 1;
+    }
+    const int depth = 2;
+    const size_t unit = direction == BWTGPU_FORWARD ? block_size : block_size + 1;
+    const size_t slab_blocks = slab_blocks_for(unit, remaining_bytes);
+    const bool trace = std::getenv("BWT_HOST_TRACE") != nullptr;
+    enum State { Free, Filled, Submitted };
+    struct Slot {
+        State st = Free;
+        size_t bytes = 0;
+    };
+    const size_t kNone = (size_t)-1;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slot> ring((size_t)ndev * (size_t)depth);
+    std::vector<PipelineCache::Lease> leases((size_t)ndev);
+    std::vector<bwtgpu_pipeline*> pipes((size_t)ndev, nullptr);
+    size_t total = kNone;  // number of slabs, once the reader knows it
+    bool failed = false;
+    auto slot_of = [&](size_t k) -> Slot& { return ring[(k % (size_t)ndev) * (size_t)depth + (k / (size_t)ndev) % (size_t)depth]; };
+    auto fail_with = [&](const std::string& msg) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!failed) std::cerr << "Error: " << msg << std::endl;
+        failed = true;
+        cv.notify_all();
+    };
+
+    auto submitter = [&](int dev) {
+        for (size_t k = (size_t)dev;; k += (size_t)ndev) {
+            size_t bytes;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return failed || slot_of(k).st == Filled || (total != kNone && k >= total); });
+                if (failed || slot_of(k).st != Filled) return;
+                bytes = slot_of(k).bytes;
+            }
+            const int slot = (int)((k / (size_t)ndev) % (size_t)depth);
+            if (bwtgpu_pipeline_submit(pipes[(size_t)dev], slot, bytes, delimiter) != BWTGPU_OK) {
+                fail_with(bwtgpu_last_error());
+                return;
+            }
+            std::lock_guard<std::mutex> lock(mu);
+            slot_of(k).st = Submitted;
+            cv.notify_all();
+        }
+    };
+    double t_wait = 0, t_write = 0, t_read = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto writer = [&] {
+        for (size_t k = 0;; ++k) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return failed || slot_of(k).st == Submitted || (total != kNone && k >= total); });
+                if (failed || slot_of(k).st != Submitted) return;
+            }
+            const int dev = (int)(k % (size_t)ndev), slot = (int)((k / (size_t)ndev) % (size_t)depth);
+            const uint8_t* out = nullptr;
+            size_t n = 0;
+            const double t0 = now();
+            if (bwtgpu_pipeline_collect(pipes[(size_t)dev], slot, &out, &n) != BWTGPU_OK) {
+                fail_with(bwtgpu_last_error());
+                return;
+            }
+            const double t1 = now();
+            if (!processor.write_bytes(reinterpret_cast<const char*>(out), n)) {
+                fail_with("short write to the output file");
+                return;
+            }
+            t_wait += t1 - t0;
+            t_write += now() - t1;
+            std::lock_guard<std::mutex> lock(mu);
+            slot_of(k).st = Free;
+            cv.notify_all();
+        }
+    };
+
+    std::vector<std::thread> threads;
+    std::thread writer_thread(writer);
+    for (size_t k = 0;; ++k) {
+        const int dev = (int)(k % (size_t)ndev), slot = (int)((k / (size_t)ndev) % (size_t)depth);
+        {
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&] { return failed || slot_of(k).st == Free; });
+            if (failed) break;
+        }
+        if (!pipes[(size_t)dev]) {  // first slab for this GPU: its pipeline and its submitting thread
+            leases[(size_t)dev] = PipelineCache::instance().acquire(dev, direction, block_size, slab_blocks, depth);
+            pipes[(size_t)dev] = leases[(size_t)dev].p;
+            if (!pipes[(size_t)dev]) {
+                fail_with(bwtgpu_last_error());
+                break;
+            }
+            threads.emplace_back(submitter, dev);
+        }
+        bwtgpu_pipeline* p = pipes[(size_t)dev];
+        const size_t cap = bwtgpu_pipeline_input_capacity(p);
+        const double t0 = now();
+        const size_t got = processor.read_bytes(reinterpret_cast<char*>(bwtgpu_pipeline_input(p, slot)), cap);
+        t_read += now() - t0;
+        std::lock_guard<std::mutex> lock(mu);
+        if (got == 0) {
+            total = k;
+        } else {
+            slot_of(k).bytes = got;
+            slot_of(k).st = Filled;
+            if (got < cap) total = k + 1;
+        }
+        cv.notify_all();
+        if (total != kNone) break;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (total == kNone) total = 0;  // only after a failure: lets the waiting threads go
+        cv.notify_all();
+    }
+    for (std::thread& t : threads) t.join();
+    writer_thread.join();
+    if (trace)
+        std::fprintf(stderr, "bwt host: %d GPU(s), read %.3f s (reader thread), wait %.3f, write %.3f s (writer thread), slabs of %zu blocks\n",
+                     ndev, t_read, t_wait, t_write, slab_blocks);
+    for (size_t d = 0; d < pipes.size(); ++d) {
+        if (!pipes[d]) continue;
+        if (failed) bwtgpu_pipeline_destroy(pipes[d]);  // do not reuse a pipeline that reported an error
+        else PipelineCache::instance().release(leases[d], (int)d, direction, block_size, depth);
+    }
+    return failed ? 1 : 0;
+}
+
+inline int run_slabs(FileProcessor& processor, int direction, size_t block_size, unsigned char delimiter,
+                     size_t remaining_bytes) {
+    const size_t unit = direction == BWTGPU_FORWARD ? block_size : block_size + 1;
+    const bool one_slab = processor.input_is_regular() && remaining_bytes <= slab_blocks_for(unit, remaining_bytes) * unit;
+    if (one_slab || std::getenv("BWT_HOST_SERIAL")) return run_slabs_serial(processor, direction, block_size, delimiter, remaining_bytes);
+    return run_slabs_threaded(processor, direction, block_size, delimiter, remaining_bytes);
 }
 
 }  // namespace bwt_host

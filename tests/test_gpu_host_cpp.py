@@ -120,6 +120,37 @@ def test_two_slab_pipeline_depth(tmp_path):
         assert got == want, blk
     assert run([os.path.join(BUILD, "inverse_bwt"), f, b, "512"]).returncode == 0
     assert np.array_equal(np.fromfile(b, dtype=np.uint8), data)
+    # The same file driven by the calling thread alone (multi-slab files normally get a reading thread,
+    # one submitting thread per GPU and a writing thread) and with more GPUs asked for than there are:
+    # identical bytes both ways.
+    for env in ({"BWT_HOST_SERIAL": "1"}, {"BWT_DEVICES": "8"}):
+        f2, b2 = str(tmp_path / "big2.bwt"), str(tmp_path / "big2.out")
+        e = dict(os.environ, **env)
+        assert subprocess.run([os.path.join(BUILD, "bwt"), src, f2, "512"], cwd=ROOT, env=e, timeout=600).returncode == 0
+        assert open(f2, "rb").read() == open(f, "rb").read()
+        assert subprocess.run([os.path.join(BUILD, "inverse_bwt"), f2, b2, "512"], cwd=ROOT, env=e, timeout=600).returncode == 0
+        assert np.array_equal(np.fromfile(b2, dtype=np.uint8), data)
+
+
+def test_threaded_runner_reports_errors(tmp_path):
+    """A multi-slab inverse whose second slab holds a block without delimiter: exit code 1 and a message,
+    no hang (reader, submitters and writer all stop)."""
+    import numpy as np
+
+    from bwt_amd import synth
+
+    data = synth.generate("acgt", 9, 0, 20 * (1 << 20))
+    src, f, b = str(tmp_path / "d"), str(tmp_path / "d.bwt"), str(tmp_path / "d.out")
+    data.tofile(src)
+    assert run([os.path.join(BUILD, "bwt"), src, f, "512"]).returncode == 0
+    raw = np.fromfile(f, dtype=np.uint8)
+    delim = int(raw[0])
+    blk = 33000  # in the second 16 MiB slab
+    seg = raw[1 + blk * 513:1 + (blk + 1) * 513]
+    seg[seg == delim] = ord("A")
+    raw.tofile(f)
+    r = run([os.path.join(BUILD, "inverse_bwt"), f, b, "512"])
+    assert r.returncode == 1 and "delimiter" in r.stderr
 
 
 def _sample_blocks_equal_oracle(data, out, bs, delim, blocks):
