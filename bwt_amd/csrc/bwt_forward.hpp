@@ -129,7 +129,7 @@ struct FwdShared {
     } u;
     union {
         uint8_t lut[kFine];             // round 0: fine bin -> bucket id
-        uint32_t cw[8 * NT];            // LDS bucket sort: 16 counters of 16 bits per thread
+        uint32_t cw[8 * NT + NT / 4];   // LDS bucket sort: 8 counter words per thread; word L of the (row, thread) order sits at L + L / 32
     } v;
     uint32_t hist[2][W * kBins];    // per-wave digit counts / scatter offsets, double buffered
     uint8_t sym[256];               // byte value -> code
@@ -376,8 +376,13 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
     const bool active = (uint32_t)tid < nthr;
     const int P = (bits + kLdsDigitBits - 1) / kLdsDigitBits;
     const int db = (bits + P - 1) / P;
+    // Counter word L = row * NT + thread lives at L + L / 32: a thread's own words (one per row) stay a
+    // lane apart, and the 8 consecutive words a thread scans no longer start 32 bytes apart from its
+    // neighbours' (an 8-way bank conflict on every scan access), but 33.
+    constexpr int RS = NT + NT / 32;  // physical distance of two rows
     uint32_t* cw = sh.v.cw;
-    uint32_t* mycw = cw + tid;
+    uint32_t* mycw = cw + tid + tid / 32;
+    uint32_t* scan8 = cw + 8 * tid + tid / 4;
     uint64_t* ls = sh.u.lsort;
     const uint64_t* mine = ls + (uint32_t)tid * (uint32_t)V;
     auto digit = [&](uint64_t y, int o) {  // o = bit offset of the digit inside the 64-bit word
@@ -387,7 +392,7 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
     for (int p = 0; p < P; ++p) {
         const int o = 64 - bits + p * db;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) mycw[i * NT] = 0;
+        for (int i = 0; i < 8; ++i) mycw[i * RS] = 0;
         __syncthreads();  // counters cleared, previous pass (or the staging) landed in ls
         uint64_t e[V];
         uint32_t old[V];
@@ -397,7 +402,7 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const uint32_t d = digit(e[j], o);
-                old[j] = atomicAdd(&mycw[(d & 7u) * NT], 1u << ((d << 1) & 16u));
+                old[j] = atomicAdd(&mycw[(d & 7u) * RS], 1u << ((d << 1) & 16u));
             }
         }
         __syncthreads();
@@ -406,7 +411,7 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
             uint32_t c[8], sum = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                c[i] = cw[8 * tid + i];
+                c[i] = scan8[i];
                 sum += c[i];
             }
             uint32_t total;
@@ -414,7 +419,7 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
             run += (total & 0xFFFFu) << 16;  // every digit >= 8 comes after all digits < 8
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                cw[8 * tid + i] = run;
+                scan8[i] = run;
                 run += c[i];
             }
         }
@@ -422,7 +427,7 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
         if (active) {
             uint32_t off[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) off[j] = mycw[(digit(e[j], o) & 7u) * NT];
+            for (int j = 0; j < V; ++j) off[j] = mycw[(digit(e[j], o) & 7u) * RS];
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 // run start and my rank inside it sit in the same half of their words
