@@ -102,7 +102,8 @@ struct InvArgs {
     uint2* chain;         // per block: x = segments on the chain, y = bytes they produce
     uint32_t split_shift; // log2 of the rows between regular splitters
     uint32_t slot;        // bytes of staging per segment (power of two); longer segments chain pool chunks of the same size
-    uint8_t* stage;       // nblocks * seg_cap * slot: the first `slot` bytes of every segment, in walk order
+    uint8_t* stage;       // nblocks * stage_cap * slot: the first `slot` bytes of every segment, in walk order (stage_group)
+    uint32_t stage_cap;   // seg_cap rounded up to a multiple of 64
     uint32_t* seg_ovf;    // nblocks * seg_cap: first pool chunk of a segment longer than a slot (valid only then)
     uint32_t chunk_cap;   // pool chunks per block
     uint32_t* pool_used;  // per block: chunks handed out
@@ -148,6 +149,15 @@ __device__ __host__ __forceinline__ uint32_t regular_splitters(uint32_t n, uint3
 // Row -> splitter id (a splitter iff below regular_splitters) and id -> row.
 __device__ __forceinline__ uint32_t mul_mod(uint32_t x, uint32_t m, uint32_t n) {
     return (uint32_t)(((uint64_t)x * m) % n);
+}
+
+// Staging of the first `slot` bytes of segment j of block b, in 16-byte groups.  The 64 segments that
+// one wave walks fill their q-th groups in the same step, so those lie side by side (one 1 KiB run per
+// step instead of 64 stores that each touch a line of their own): group q of segment j is at
+// stage_group(a, b, j) + q * kStageGroupStride.
+constexpr uint32_t kStageGroupStride = 64u * 16u;
+__device__ __forceinline__ uint8_t* stage_group(const InvArgs& a, uint32_t b, uint32_t j) {
+    return a.stage + ((uint64_t)b * a.stage_cap + (j & ~63u)) * a.slot + (j & 63u) * 16u;
 }
 
 template <int NT>
@@ -590,7 +600,8 @@ __global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel
     }
     const TW* __restrict__ T = (const TW*)a.T + (uint64_t)b * a.tstride;
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
-    uint8_t* buf = a.stage + (sb + j) * a.slot;
+    uint8_t* buf = stage_group(a, b, j);
+    uint32_t gstride = kStageGroupStride;  // distance of the 16-byte groups: side by side in a pool chunk
     uint32_t prevc = 0;
     uint32_t row = TableWord<TW>::row(T[start]);
     uint32_t t = 0;  // bytes the segment produces
@@ -611,6 +622,7 @@ __global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel
             else a.chunk_next[pb + prevc] = c;
             prevc = c;
             buf = a.pool + (pb + c) * a.slot;
+            gstride = 16u;
         }
         acc |= TableWord<TW>::byte(wd) << (8u * (t & 3u));
         ++t;
@@ -619,7 +631,7 @@ __global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel
             acc = 0;
             if ((t & 15u) == 0u) {
                 const v4 val = {q0, q1, q2, q3};
-                __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t - 16u) & (a.slot - 1u))));
+                __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + (((t - 16u) & (a.slot - 1u)) >> 4) * gstride));
             }
         }
         if (at_splitter) {  // a splitter's own byte belongs to the segment that reaches it
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel
         else if (have == 1) { val.x = q3; val.y = acc; }
         else if (have == 2) { val.x = q2; val.y = q3; val.z = acc; }
         else { val.x = q1; val.y = q2; val.z = q3; val.w = acc; }
-        __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + ((t & ~15u) & (a.slot - 1u))));
+        __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + (((t & ~15u) & (a.slot - 1u)) >> 4) * gstride));
     }
     a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : mul_mod(stop, a.split_mul[last], n));
 }
@@ -805,7 +817,8 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
 __device__ __forceinline__ void place_segment_direct(const InvArgs& a, uint32_t b, uint32_t j, uint32_t pos,
                                                      uint32_t len, uint32_t n, uint64_t sb) {
     const uint64_t pb = (uint64_t)b * a.chunk_cap;
-    const uint8_t* src = a.stage + (sb + j) * a.slot;
+    const uint8_t* src = stage_group(a, b, j);
+    uint32_t gstride = kStageGroupStride;
     uint32_t c = 0;
     BackWriter bw;
     bw.init(a.out + (uint64_t)b * a.out_stride + (n - 1) - pos);
@@ -822,9 +835,10 @@ __device__ __forceinline__ void place_segment_direct(const InvArgs& a, uint32_t 
             c = g == (a.slot / 16u) ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
             if (c >= a.chunk_cap) break;  // never
             src = a.pool + (pb + c) * a.slot;
+            gstride = 16u;
         }
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + ((16u * g) & (a.slot - 1u)));
+        if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + (g & ((a.slot / 16u) - 1u)) * gstride);
         if (g == 0) {
             for (uint32_t k = 0; k < head; ++k) bw.push((v.x >> (8u * k)) & 255u);
         }
@@ -896,7 +910,8 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
         const uint32_t head = min(len, (4u - (d0 & 3u)) & 3u);
         const uint32_t nd = (len - head) >> 2, tail = len - head - 4u * nd;
         const uint64_t pb = (uint64_t)b * a.chunk_cap;
-        const uint8_t* src = a.stage + (sb + j) * a.slot;
+        const uint8_t* src = stage_group(a, b, j);
+        uint32_t gstride = kStageGroupStride;
         uint32_t c = 0, prev = 0;
         const uint32_t last_group = (nd + 1u) >> 2;      // source dwords 0 .. nd+1 are consulted
         uint32_t* const ld = s_buf + ((d0 + head) >> 2);
@@ -905,9 +920,10 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
                 c = g == (a.slot / 16u) ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
                 if (c >= a.chunk_cap) break;  // never
                 src = a.pool + (pb + c) * a.slot;
+                gstride = 16u;
             }
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + ((16u * g) & (a.slot - 1u)));
+            if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + (g & ((a.slot / 16u) - 1u)) * gstride);
             if (g == 0) {
                 for (uint32_t t = 0; t < head; ++t) lb[d0 + t] = (uint8_t)(v.x >> (8u * t));
             }

@@ -308,7 +308,7 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.segrec_off = take(g.split ? g.nblocks * g.seg_cap * 8 : 0);
     g.segovf_off = take(g.nblocks * g.seg_cap * 4);
     g.next_off = take(g.nblocks * (size_t)g.chunk_cap * 4);
-    g.stage_off = take(g.split ? g.nblocks * (size_t)g.seg_cap * g.slot : 0);
+    g.stage_off = take(g.split ? g.nblocks * round_up(g.seg_cap, 64) * g.slot : 0);
     g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * g.slot : 0);
     g.t_off = take((size_t)g.tstride * (g.wide ? 8 : 4) * g.nblocks);
     g.bytes = off;
@@ -872,6 +872,7 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
     a.seg_rec = (uint2*)(ws + g.segrec_off);
     a.chain = (uint2*)(ws + g.chain_off);
     a.stage = ws + g.stage_off;
+    a.stage_cap = (uint32_t)round_up(g.seg_cap, 64);
     a.seg_ovf = (uint32_t*)(ws + g.segovf_off);
     a.chunk_cap = g.chunk_cap;
     a.pool_used = (uint32_t*)(ws + g.used_off);
