@@ -704,9 +704,75 @@ __device__ __forceinline__ uint2 order_supers(uint32_t last, uint32_t* s_sum, ui
     return make_uint2(segs, bytes);
 }
 
+// The same by the whole workgroup when, as in every block the forward transform made, the super nodes
+// form ONE chain from the delimiter's node through all of them: log2 rounds of pointer jumping give
+// every node the bytes, segments and nodes from itself to the chain's end, and what lies before a node
+// is the total minus that.  (One thread following some 500 links, each a dependent LDS access, was
+// half the stitch kernel's time.)  Returns false, with the arrays as they were, when the nodes do not
+// form such a chain (hand-made blocks); the caller then orders them with order_supers.
+// s_nxt / s_hops: scratch of last + 1 words each.  All threads of the workgroup must call.
+template <int NT>
+__device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s_sum, uint32_t* s_nc, uint32_t* s_pos,
+                                                      uint32_t* s_nxt, uint32_t* s_hops, uint2* whole) {
+    const uint32_t u = threadIdx.x;
+    const bool mine = u <= last;
+    if (last + 1u > (uint32_t)NT) return false;  // workgroup-uniform
+    uint32_t bytes = 0, segs = 0, hops = 1, nx = kSuperNone;
+    if (mine) {
+        bytes = s_sum[u];
+        segs = s_nc[u] >> 13;
+        nx = s_nc[u] & kSuperNone;
+        if (nx == last) nx = kSuperNone;  // back at the delimiter row: the text is complete
+        s_pos[u] = bytes;
+        s_hops[u] = (segs << 10) | 1u;    // segments (at most 2^17 per block) above the node count (at most 2^10)
+        s_nxt[u] = nx;
+    }
+    __syncthreads();
+    const uint32_t own_bytes = bytes, own_segs = segs;
+    for (uint32_t span = 1; span <= last; span <<= 1) {
+        uint32_t b2 = 0, h2 = 0, n2 = kSuperNone;
+        if (mine && nx != kSuperNone) {
+            b2 = s_pos[nx];
+            h2 = s_hops[nx];
+            n2 = s_nxt[nx];
+        }
+        __syncthreads();
+        if (mine && nx != kSuperNone) {
+            bytes += b2;
+            segs += h2 >> 10;
+            hops += h2 & 1023u;
+            nx = n2;
+            s_pos[u] = bytes;
+            s_hops[u] = (segs << 10) | (hops & 1023u);
+            s_nxt[u] = nx;
+        }
+        __syncthreads();
+    }
+    // one chain through all nodes: everybody has reached the end, and the head counts them all
+    const uint32_t head_hops = s_hops[last] & 1023u;
+    const bool ok = __syncthreads_and(!mine || nx == kSuperNone) && head_hops == ((last + 1u) & 1023u) && last + 1u < 1024u;
+    const uint32_t tot_bytes = s_pos[last], tot_segs = s_hops[last] >> 10;
+    __syncthreads();
+    if (!ok) {
+        if (mine) s_pos[u] = kNoPos;  // as the caller left it
+        __syncthreads();
+        return false;
+    }
+    if (mine) {
+        s_pos[u] = tot_bytes - bytes;   // bytes before this node's chain
+        s_sum[u] = tot_segs - segs;     // ordinal of its first segment
+    }
+    *whole = make_uint2(tot_segs, tot_bytes);
+    (void)own_bytes;
+    (void)own_segs;
+    __syncthreads();
+    return true;
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     __shared__ uint32_t s_sum[kMaxSupers], s_nc[kMaxSupers], s_pos[kMaxSupers];
+    __shared__ uint32_t s_nxt[NT], s_hops[NT];
     const uint32_t b = blockIdx.x;
     if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
@@ -725,8 +791,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
         s_pos[u] = kNoPos;
     }
     __syncthreads();
+    uint2 whole;
+    const bool chained = order_supers_parallel<NT>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);  // blocks of up to NT super nodes
     if (threadIdx.x == 0) {
-        const uint2 whole = order_supers(last, s_sum, s_nc, s_pos);
+        if (!chained) whole = order_supers(last, s_sum, s_nc, s_pos);
         a.chain[b] = whole;
         a.lens[b] = whole.y < n ? whole.y : n - 1;
     }
@@ -757,6 +825,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
     __shared__ uint2 s_seg[kStitchLdsSegs];
     __shared__ uint32_t s_sum[kStitchLdsSupers], s_nc[kStitchLdsSupers], s_pos[kStitchLdsSupers];
+    __shared__ uint32_t s_nxt[kStitchLdsSupers], s_hops[kStitchLdsSupers];
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
         if (a.mode[b] != kModeMulti) continue;  // workgroup-uniform
         const uint32_t n = inv_block_len(a, b);
@@ -777,8 +846,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
             s_pos[u] = kNoPos;
         }
         __syncthreads();
+        uint2 whole;
+        const bool chained = order_supers_parallel<NT>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);
         if (threadIdx.x == 0) {
-            const uint2 whole = order_supers(last, s_sum, s_nc, s_pos);
+            if (!chained) whole = order_supers(last, s_sum, s_nc, s_pos);
             a.chain[b] = whole;
             a.lens[b] = whole.y < n ? whole.y : n - 1;
         }
