@@ -666,7 +666,7 @@ __device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* p, const u
 // bytes that start at q0 + m0 - 17, pushes one symbol code per step into a shift register
 // and, from step 16 on, the register holds the key of position q0 + (step - 16).
 template <int NT, int MODE>
-__device__ __forceinline__ void round0_sweep(const Round0& r, const BucketDigit& dig, const BucketDigit& nxt,
+__device__ __noinline__ void round0_sweep(const Round0 r, const BucketDigit dig, const BucketDigit nxt,
                                              bool has_next, uint64_t* __restrict__ dst, FwdShared<NT>& sh, int sel,
                                              uint32_t* err) {
     constexpr int W = NT / kWave;
@@ -1265,18 +1265,34 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
 template <int U>
 __device__ __forceinline__ void suffix_keys(const Round0& r, const uint8_t* sym, const uint32_t (&j)[U],
                                             uint64_t (&key)[U]) {
+    // the m0 <= 17 bytes at j[u] .. : six aligned dwords per suffix, all loads in flight together
+    // (byte after byte, each waiting for the one before, was most of the time of a lookup)
+    static_assert(kMaxM0 <= 20, "the window of a key fits five dwords after alignment");
+    uint32_t win[U][5];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint8_t* p = r.s + min(j[u], r.len - 1u);  // len >= 1 here
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+        const uint8_t* ap = p - mis;
+        uint32_t raw[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) raw[k] = load_dword_guarded(ap + 4 * k, r.g_lo, r.g_hi);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) win[u][k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], mis);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) key[u] = 0;
-    for (int t = 0; t < r.m0; ++t) {
-        uint32_t byte[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) byte[u] = r.s[min(j[u] + (uint32_t)t, r.len - 1u)];  // len >= 1 here
+    for (int t = 0; t < kMaxM0; ++t) {
+        if (t < r.m0) {  // workgroup-uniform
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p = j[u] + (uint32_t)t;
-            uint32_t c = (uint32_t)sym[byte[u]];
-            if (p >= r.len) c = (p == r.len) ? r.dcode : r.pad;
-            key[u] = (key[u] << r.sbits) | c;
+            for (int u = 0; u < U; ++u) {
+                const uint32_t p = j[u] + (uint32_t)t;
+                const uint32_t byte = (win[u][t >> 2] >> (8 * (t & 3))) & 255u;
+                uint32_t c = (uint32_t)sym[byte];
+                if (p >= r.len) c = (p == r.len) ? r.dcode : r.pad;
+                key[u] = (key[u] << r.sbits) | c;
+            }
         }
     }
 #pragma unroll
