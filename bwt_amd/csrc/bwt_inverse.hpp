@@ -718,60 +718,81 @@ __device__ __forceinline__ uint2 order_supers(uint32_t last, uint32_t* s_sum, ui
 // half the stitch kernel's time.)  Returns false, with the arrays as they were, when the nodes do not
 // form such a chain (hand-made blocks); the caller then orders them with order_supers.
 // s_nxt / s_hops: scratch of last + 1 words each.  All threads of the workgroup must call.
-template <int NT>
+template <int NT, int K = 1>  // K: super nodes per thread (node u belongs to thread u % NT)
 __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s_sum, uint32_t* s_nc, uint32_t* s_pos,
                                                       uint32_t* s_nxt, uint32_t* s_hops, uint2* whole) {
-    const uint32_t u = threadIdx.x;
-    const bool mine = u <= last;
-    if (last + 1u > (uint32_t)NT) return false;  // workgroup-uniform
-    uint32_t bytes = 0, segs = 0, hops = 1, nx = kSuperNone;
-    if (mine) {
-        bytes = s_sum[u];
-        segs = s_nc[u] >> 13;
-        nx = s_nc[u] & kSuperNone;
-        if (nx == last) nx = kSuperNone;  // back at the delimiter row: the text is complete
-        s_pos[u] = bytes;
-        s_hops[u] = (segs << 10) | 1u;    // segments (at most 2^17 per block) above the node count (at most 2^10)
-        s_nxt[u] = nx;
+    if (last + 1u > (uint32_t)(NT * K) || last + 1u >= 8192u) return false;  // workgroup-uniform
+    uint32_t bytes[K], segs[K], hops[K], nx[K];
+    bool mine[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t u = threadIdx.x + (uint32_t)(k * NT);
+        mine[k] = u <= last;
+        bytes[k] = segs[k] = 0;
+        hops[k] = 1;
+        nx[k] = kSuperNone;
+        if (mine[k]) {
+            bytes[k] = s_sum[u];
+            segs[k] = s_nc[u] >> 13;
+            nx[k] = s_nc[u] & kSuperNone;
+            if (nx[k] == last) nx[k] = kSuperNone;  // back at the delimiter row: the text is complete
+            s_pos[u] = bytes[k];
+            s_hops[u] = (segs[k] << 13) | 1u;       // segments (at most 2^17 per block) above the node count (below 2^13)
+            s_nxt[u] = nx[k];
+        }
     }
     __syncthreads();
-    const uint32_t own_bytes = bytes, own_segs = segs;
     for (uint32_t span = 1; span <= last; span <<= 1) {
-        uint32_t b2 = 0, h2 = 0, n2 = kSuperNone;
-        if (mine && nx != kSuperNone) {
-            b2 = s_pos[nx];
-            h2 = s_hops[nx];
-            n2 = s_nxt[nx];
+        uint32_t b2[K], h2[K], n2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            b2[k] = h2[k] = 0;
+            n2[k] = kSuperNone;
+            if (mine[k] && nx[k] != kSuperNone) {
+                b2[k] = s_pos[nx[k]];
+                h2[k] = s_hops[nx[k]];
+                n2[k] = s_nxt[nx[k]];
+            }
         }
         __syncthreads();
-        if (mine && nx != kSuperNone) {
-            bytes += b2;
-            segs += h2 >> 10;
-            hops += h2 & 1023u;
-            nx = n2;
-            s_pos[u] = bytes;
-            s_hops[u] = (segs << 10) | (hops & 1023u);
-            s_nxt[u] = nx;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (mine[k] && nx[k] != kSuperNone) {
+                const uint32_t u = threadIdx.x + (uint32_t)(k * NT);
+                bytes[k] += b2[k];
+                segs[k] += h2[k] >> 13;
+                hops[k] += h2[k] & 8191u;
+                nx[k] = n2[k];
+                s_pos[u] = bytes[k];
+                s_hops[u] = (segs[k] << 13) | (hops[k] & 8191u);
+                s_nxt[u] = nx[k];
+            }
         }
         __syncthreads();
     }
     // one chain through all nodes: everybody has reached the end, and the head counts them all
-    const uint32_t head_hops = s_hops[last] & 1023u;
-    const bool ok = __syncthreads_and(!mine || nx == kSuperNone) && head_hops == ((last + 1u) & 1023u) && last + 1u < 1024u;
-    const uint32_t tot_bytes = s_pos[last], tot_segs = s_hops[last] >> 10;
+    bool done = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) done = done && (!mine[k] || nx[k] == kSuperNone);
+    const uint32_t head_hops = s_hops[last] & 8191u;
+    const bool ok = __syncthreads_and(done) && head_hops == last + 1u;
+    const uint32_t tot_bytes = s_pos[last], tot_segs = s_hops[last] >> 13;
     __syncthreads();
     if (!ok) {
-        if (mine) s_pos[u] = kNoPos;  // as the caller left it
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (mine[k]) s_pos[threadIdx.x + (uint32_t)(k * NT)] = kNoPos;  // as the caller left it
         __syncthreads();
         return false;
     }
-    if (mine) {
-        s_pos[u] = tot_bytes - bytes;   // bytes before this node's chain
-        s_sum[u] = tot_segs - segs;     // ordinal of its first segment
-    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (mine[k]) {
+            const uint32_t u = threadIdx.x + (uint32_t)(k * NT);
+            s_pos[u] = tot_bytes - bytes[k];   // bytes before this node's chain
+            s_sum[u] = tot_segs - segs[k];     // ordinal of its first segment
+        }
     *whole = make_uint2(tot_segs, tot_bytes);
-    (void)own_bytes;
-    (void)own_segs;
     __syncthreads();
     return true;
 }
@@ -779,7 +800,8 @@ __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     __shared__ uint32_t s_sum[kMaxSupers], s_nc[kMaxSupers], s_pos[kMaxSupers];
-    __shared__ uint32_t s_nxt[NT], s_hops[NT];
+    constexpr int K = NT >= 1024 ? 4 : 1;  // super nodes per thread in the parallel ordering
+    __shared__ uint32_t s_nxt[NT * K], s_hops[NT * K];
     const uint32_t b = blockIdx.x;
     if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
@@ -799,7 +821,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     }
     __syncthreads();
     uint2 whole;
-    const bool chained = order_supers_parallel<NT>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);  // blocks of up to NT super nodes
+    const bool chained = order_supers_parallel<NT, K>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);  // blocks of up to NT * K super nodes
     if (threadIdx.x == 0) {
         if (!chained) whole = order_supers(last, s_sum, s_nc, s_pos);
         a.chain[b] = whole;
