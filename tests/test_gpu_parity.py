@@ -89,6 +89,14 @@ def test_inverse_errors_and_misuse(orc):
     # several delimiters: the walk starts at the last one and stops at the first it reaches
     for blk in [b"~~aabb", b"~~~", b"a~b~c~", b"~"]:
         assert api.bwt_inverse(blk, ord("~")) == orc.inverse(blk, ord("~")), blk
+    # a long block with exactly one delimiter that is nobody's transform: its LF permutation has several
+    # cycles, and the text is what the cycle through the delimiter row spells (the segmented walk's chain
+    # of segments then does not pass through all of them)
+    rng = random.Random(77)
+    for n, sigma in [(5000, 4), (70000, 3), (300000, 200)]:
+        blk = bytearray(rng.randrange(1, 1 + sigma) for _ in range(n))
+        blk[rng.randrange(n)] = 0
+        assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0), (n, sigma)
     with pytest.raises(api.BwtGpuError) as e:
         api.forward_batch(b"abc", 0, 0)
     assert e.value.code == api.ERR_INVALID
