@@ -70,7 +70,7 @@ struct FwdCfg {
     static constexpr int kTileVecs = NT <= 256 ? 13 : 8;
     static constexpr int kTileElems = kTileVecs * kWave;
     // elements per thread in an LDS bucket sort (odd, see lds_sort_bucket)
-    static constexpr int kSortVecs = NT <= 256 ? 19 : 5;
+    static constexpr int kSortVecs = NT <= 256 ? 17 : 5;
 };
 constexpr int kFineBits = 13;        // round 0: the top bits of the key that choose a fine bin
 constexpr int kFine = 1 << kFineBits;
