@@ -52,8 +52,10 @@ struct FwdArgs {
     uint8_t* ws;          // workgroup w owns ws + w*ws_stride
     uint64_t ws_stride;
     uint32_t* queue;      // [0] next block index to hand out, [1] error flags, [2] blocks put off, [3] next put-off
-                          // block to hand out, [16..] phase clocks
+                          // block to hand out, [4] next entry of `normal` to hand out, [5] entries of `normal`,
+                          // [6] next block to classify, [16..] phase clocks
     uint32_t* deferred;   // nblocks words: the blocks the first launch put off for the second
+    uint32_t* normal;     // nblocks words: with a classifying launch first, the blocks it leaves to the first launch
 };
 
 constexpr uint32_t kErrNotConverged = 1u;
@@ -2168,9 +2170,13 @@ constexpr uint32_t kShortTailMinPeriod = 8192;  // ... i.e. at least this (short
 // them the search gives up (the block is then sorted like any other).
 constexpr uint32_t kPeriodTries = 16;
 
-template <int NT>
+struct PeriodWords {  // the two LDS words the search needs (FwdShared has them too)
+    uint32_t period_cand, period_bad;
+};
+
+template <int NT, typename Shared>
 __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__ s, uint32_t len, const uint8_t* g_lo,
-                                                      const uint8_t* g_hi, FwdShared<NT>& sh) {
+                                                      const uint8_t* g_hi, Shared& sh) {
     const int tid = threadIdx.x, lane = lane_id();
     if (len < 16384u) return 0;  // workgroup-uniform (the windows below reach 4 KiB + len / 3 into the block)
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3u);
@@ -2895,18 +2901,49 @@ __global__ __launch_bounds__(NT, NT <= 256 ? 3 : 4) void bwt_forward_kernel(FwdA
     uint64_t* bufB = bufA + a.ncap;
     uint32_t* rank = reinterpret_cast<uint32_t*>(bufB + a.ncap);
     for (;;) {
-        // first launch: all blocks in order; second launch: the blocks the first one put off
-        if (threadIdx.x == 0) sh.blk = atomicAdd(&a.queue[second ? 3 : 0], 1u);
+        // second == 0: all blocks in order; 1: the blocks that were put off (by the launch before, or by
+        // the classifying launch); 2: the blocks the classifying launch has left to this one
+        if (threadIdx.x == 0) sh.blk = atomicAdd(&a.queue[second == 1 ? 3 : second == 2 ? 4 : 0], 1u);
         __syncthreads();
         uint32_t b = sh.blk;
         __syncthreads();
-        if (b >= (second ? a.queue[2] : a.nblocks)) break;
-        if (second) b = a.deferred[b];
+        if (b >= (second == 1 ? a.queue[2] : second == 2 ? a.queue[5] : a.nblocks)) break;
+        if (second == 1) b = a.deferred[b];
+        else if (second == 2) b = a.normal[b];
         const uint64_t off = (uint64_t)b * a.block_size;
         const uint64_t rem = a.total_len - off;
         const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;
         forward_block<NT, HEAVY>(a.in + off, len, a.delim, a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u), bufA,
                                  bufB, rank, sh, a, b);
+        __syncthreads();
+    }
+}
+
+// ---- classifying launch (long blocks) ---------------------------------------------------------------
+// A block that is periodic as a whole is only recognised by the common-case kernel after a full round 0
+// (every suffix has a twin), which for long blocks is most of what sorting it would have cost.  For
+// batches of long blocks a small launch therefore looks for whole-block periods first -- one sweep over
+// a third of each block, a full comparison only for blocks that pass it -- and sorts the blocks into
+// the two lists the sorting launches take their work from.
+template <int NT>
+__global__ __launch_bounds__(NT) void bwt_forward_classify_kernel(FwdArgs a) {
+    __shared__ PeriodWords sh;
+    __shared__ uint32_t s_blk;
+    for (;;) {
+        if (threadIdx.x == 0) s_blk = atomicAdd(&a.queue[6], 1u);
+        __syncthreads();
+        const uint32_t b = s_blk;
+        __syncthreads();
+        if (b >= a.nblocks) break;
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint64_t rem = a.total_len - off;
+        const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;
+        uint32_t P = 0;
+        if (len >= kPeriodicMinBlock) P = detect_block_period<NT>(a.in + off, len, a.in, a.in + a.total_len, sh);
+        if (threadIdx.x == 0) {
+            if (P) a.deferred[atomicAdd(&a.queue[2], 1u)] = b;
+            else a.normal[atomicAdd(&a.queue[5], 1u)] = b;
+        }
         __syncthreads();
     }
 }

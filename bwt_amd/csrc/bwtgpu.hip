@@ -146,6 +146,7 @@ struct FwdGeom {
 // batch (random bytes; text about three times that, and 0.1 ms for every further round), the
 // batch kernel 0.2 ms plus 8.5 us per KiB of ONE block (text: 25 us) as long as every block has
 // a workgroup of its own.  The former wins for up to a few dozen blocks unless they are short.
+constexpr size_t kClassifyMinBlock = (size_t)512 << 10;  // batch kernels: blocks at least this long are checked for whole-block periods before they are sorted
 constexpr size_t kGridMaxBlocks = 32;
 constexpr size_t kGridMinBlock = 20000;      // bytes in the (longest) block
 constexpr size_t kGridMaxRows = (size_t)1 << 31;
@@ -210,7 +211,7 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     // With fewer blocks than compute units most of the chip idles and a block's latency is the
     // whole cost: give every block a 1024-thread workgroup instead.
     g.wide = g.nblocks <= (size_t)d.cus && longest >= kWideMinBlock;
-    g.bytes = kHeaderBytes + g.stride * g.grid + round_up(g.nblocks * 4, 256);  // + the list of blocks put off
+    g.bytes = kHeaderBytes + g.stride * g.grid + 2 * round_up(g.nblocks * 4, 256);  // + the lists of blocks put off / left to the first launch
     // The device-wide path serves the batch itself or, when a caller sizes its workspace for a
     // full slab and then submits a shorter one, any prefix of it.
     const int forced = forced_forward_path();
@@ -604,6 +605,7 @@ int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_
     a.ws_stride = g.stride;
     a.queue = (uint32_t*)ws;
     a.deferred = (uint32_t*)(ws + kHeaderBytes + g.stride * g.grid);
+    a.normal = a.deferred + round_up(g.nblocks * 4, 256) / 4;
     if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
         const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
@@ -620,7 +622,10 @@ int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_
             HIP_TRY(hipGetLastError());
             return BWTGPU_OK;
         }
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, 0);
+        // long blocks: whole-block periods are looked for up front (bwt_forward_classify_kernel)
+        const bool classify = block_size >= kClassifyMinBlock;
+        if (classify) hipLaunchKernelGGL(bwt_forward_classify_kernel<256>, dim3((uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus * 8)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, classify ? 2 : 0);
         // debugging aid: BWTGPU_PHASES=second makes the phase clocks in the header cover the second launch only
         static const bool second_only = std::getenv("BWTGPU_PHASES") && !strcmp(std::getenv("BWTGPU_PHASES"), "second");
         if (second_only) HIP_TRY(hipMemsetAsync(ws + 64, 0, kHeaderBytes - 64, s));
@@ -803,7 +808,7 @@ int bwtgpu_forward_batch_static(int device, const uint8_t* d_in, size_t total_le
     // them only means less of the chip is used.
     FwdGeom g = fwd_geom(d, total_len, block_size);
     if (g.nblocks > 0xFFFFFFF0ull) return fail(BWTGPU_ERR_INVALID, "too many blocks in one batch");
-    const size_t fixed = kHeaderBytes + round_up(g.nblocks * 4, 256);
+    const size_t fixed = kHeaderBytes + 2 * round_up(g.nblocks * 4, 256);  // header and the two block lists
     const size_t slices = fixed < kStaticScratchBytes ? (kStaticScratchBytes - fixed) / g.stride : 0;
     if (slices == 0)
         return fail(BWTGPU_ERR_WORKSPACE,

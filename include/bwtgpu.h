@@ -96,7 +96,7 @@ int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t
  * bwtgpu_forward_batch_device, but the scratch is a fixed array of BWTGPU_STATIC_SCRATCH_BYTES that
  * lives in the library's code object on every GPU (each GPU holds its copy until the process ends),
  * and the call itself allocates nothing, on host or device.  Limits: block_size (after clamping to
- * the batch) at most 2 MiB - 1 (BWTGPU_ERR_BLOCK_TOO_LARGE), and the batch's block list (4 bytes per
+ * the batch) at most 2 MiB - 1 (BWTGPU_ERR_BLOCK_TOO_LARGE), and the batch's block lists (8 bytes per
  * block) plus one block's slice (20 bytes per block byte) must fit the array (BWTGPU_ERR_WORKSPACE).
  * Throughput is lower than with a caller-sized workspace: only as many blocks are in flight as
  * slices fit (49 at 64 KiB blocks, 12 at 256 KiB, 3 at 1 MiB); batches of few large blocks do not
