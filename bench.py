@@ -230,6 +230,9 @@ def main() -> None:
         phase_share = {k: round(float(v) / tot, 4) for k, v in zip(names, ph) if k}
         phase_share["later_rounds_per_block"] = round(float(ph[9]) / max(1.0, float(ph[8])), 3)
         phase_share["short_stretch_given_up"] = [int(ph[21]), int(ph[22])]
+        inv_clk = d_ws_i[64:64 + 128].cpu().numpy().view("uint64")  # debug builds of the library only
+        if inv_clk.any():
+            phase_share["inverse_stitch_clocks"] = [int(v) for v in inv_clk]
         ok = torch.tensor([int(roundtrip_ok and lens_ok and int(status[1]) == 0)], device=dev)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

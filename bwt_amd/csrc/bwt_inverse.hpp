@@ -664,14 +664,23 @@ __global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel
 // order, each with the bytes before it counted from the END of the text (the walk produces the
 // text back to front).
 // One workgroup per block.  Following thousands of links one after the other would take
-// milliseconds, so every kSuperStride-th segment (and the delimiter's) is a "super" node:
-// each thread follows the links from its super node to the next one, summing the lengths
-// (short independent chains), one thread then orders the few hundred super nodes, and each
-// thread walks its chain again to hand out the ordinals and positions.
-constexpr uint32_t kSuperStride = 32;
-constexpr uint32_t kMaxSupers = kMaxSegments / kSuperStride + 2u;
+// milliseconds, so every S-th segment (and the delimiter's) is a "super" node: each thread
+// follows the links from its super node to the next one, summing the lengths (short independent
+// chains), the workgroup then orders the super nodes, and each thread walks its chain again to
+// hand out the ordinals and positions.  A chain ends at the first segment whose id is a multiple
+// of S, and the ids along a chain are as good as random: the chains' lengths are geometric with
+// mean S, and the longest of them, about S ln(segments / S), sets the pace of both walks.  So S
+// is the smallest power of two, from 8 up, whose super nodes the workgroup's tables hold.
+constexpr uint32_t kMinSuperShift = 3;
 constexpr uint32_t kSuperNone = 0x1FFFu;  // "no next super node" in the packed word below
-static_assert(kMaxSupers < kSuperNone && kMaxSegments < (1u << 18), "next super node in 13 bits, segment count above it");
+constexpr uint32_t kStitchSmallSegs = 8192;  // segments of a block, at most, for the 256-thread stitch kernel
+static_assert(kMaxSegments < (1u << 18), "next super node in 13 bits, segment count above it");
+// log2 of the super-node stride for a block of nreg regular segments and tables of `supers` entries
+__device__ __forceinline__ uint32_t super_shift(uint32_t nreg, uint32_t supers) {
+    uint32_t sh = kMinSuperShift;
+    while (((nreg + (1u << sh) - 1u) >> sh) + 1u > supers) ++sh;
+    return sh;
+}
 
 // What a super node's chain adds up to: bytes, segments, and the super node it ends at.
 struct SuperChain {
@@ -799,22 +808,26 @@ __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s
 
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
-    __shared__ uint32_t s_sum[kMaxSupers], s_nc[kMaxSupers], s_pos[kMaxSupers];
-    constexpr int K = NT >= 1024 ? 4 : 1;  // super nodes per thread in the parallel ordering
-    __shared__ uint32_t s_nxt[NT * K], s_hops[NT * K];
+    // 256 threads: blocks of at most kStitchSmallSegs segments (stride 8: 1025 super nodes);
+    // 1024 threads: up to kMaxSegments (stride 32: 4097; 1 MiB blocks get stride 16)
+    constexpr uint32_t kSupers = NT >= 1024 ? kMaxSegments / 32u + 2u : (kStitchSmallSegs >> kMinSuperShift) + 2u;
+    constexpr int K = (int)((kSupers + NT - 1) / NT);  // super nodes per thread in the parallel ordering
+    static_assert(kSupers < kSuperNone, "next super node in 13 bits");
+    __shared__ uint32_t s_sum[kSupers], s_nc[kSupers], s_pos[kSupers], s_nxt[kSupers], s_hops[kSupers];
     const uint32_t b = blockIdx.x;
     if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
     const uint32_t nreg = regular_splitters(n, a.split_shift);
     const uint64_t sb = (uint64_t)b * a.seg_cap;
-    const uint32_t last = (nreg + kSuperStride - 1u) / kSuperStride;  // super index of the delimiter's segment
+    const uint32_t sshift = super_shift(nreg, kSupers), smask = (1u << sshift) - 1u;
+    const uint32_t last = (nreg + smask) >> sshift;  // super index of the delimiter's segment
     auto super_of = [&](uint32_t id) {  // super index of segment id, or kNoPos
         if (id >= nreg) return last;
-        return (id % kSuperStride) == 0u ? id / kSuperStride : kNoPos;
+        return (id & smask) == 0u ? id >> sshift : kNoPos;
     };
     auto seg_at = [&](uint32_t id) { return a.seg[sb + id]; };
     for (uint32_t u = threadIdx.x; u <= last; u += NT) {
-        const SuperChain c = follow_to_super(u == last ? nreg : u * kSuperStride, nreg, seg_at, super_of);
+        const SuperChain c = follow_to_super(u == last ? nreg : u << sshift, nreg, seg_at, super_of);
         s_sum[u] = c.bytes;
         s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
         s_pos[u] = kNoPos;
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     for (uint32_t u = threadIdx.x; u <= last; u += NT) {
         uint32_t pos = s_pos[u];
         if (pos == kNoPos) continue;  // a chain the delimiter's chain never reaches
-        uint32_t id = u == last ? nreg : u * kSuperStride, ord = s_sum[u];
+        uint32_t id = u == last ? nreg : u << sshift, ord = s_sum[u];
         for (uint32_t it = 0; it <= nreg; ++it) {
             const uint2 sg = a.seg[sb + id];
             if (ord < a.seg_cap) a.seg_rec[sb + ord] = make_uint2(id, pos);
@@ -847,11 +860,29 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
 // global memory is one random 64-byte transaction per segment and phase, in LDS it is a few
 // cycles.  For blocks of at most kStitchLdsSegs segments; one workgroup per CU.
 constexpr uint32_t kStitchLdsSegs = 16640;
-constexpr uint32_t kLdsSuperStride = 32;  // measured: 128 is slower (the longest of the chains sets the pace), 32 balances chains against the serial pass over super nodes
+constexpr uint32_t kLdsSuperStride = 16;  // stride 8 would need 42 KB of tables beside the 133 KB of records
 constexpr uint32_t kStitchLdsSupers = kStitchLdsSegs / kLdsSuperStride + 2u;
+
+// Debug builds (-DBWT_STITCH_CLOCKS) add up thread 0's clock over the kernel's steps in the workspace
+// header (64-bit words from byte 64), which bench.py prints when they are not zero.
+#ifdef BWT_STITCH_CLOCKS
+#define STITCH_CLK(p)                                                                                \
+    do {                                                                                             \
+        if (threadIdx.x == 0) {                                                                      \
+            const uint64_t t_ = __builtin_amdgcn_s_memtime();                                        \
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 8 + (p), (unsigned long long)(t_ - clk_)); \
+            clk_ = t_;                                                                               \
+        }                                                                                            \
+    } while (0)
+#else
+#define STITCH_CLK(p)
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
+#ifdef BWT_STITCH_CLOCKS
+    uint64_t clk_ = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ uint2 s_seg[kStitchLdsSegs];
     __shared__ uint32_t s_sum[kStitchLdsSupers], s_nc[kStitchLdsSupers], s_pos[kStitchLdsSupers];
     __shared__ uint32_t s_nxt[kStitchLdsSupers], s_hops[kStitchLdsSupers];
@@ -866,8 +897,10 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
             return (id % kLdsSuperStride) == 0u ? id / kLdsSuperStride : kNoPos;
         };
         auto seg_at = [&](uint32_t id) { return s_seg[id]; };
+        STITCH_CLK(0);
         for (uint32_t i = threadIdx.x; i <= nreg; i += NT) s_seg[i] = a.seg[sb + i];
         __syncthreads();
+        STITCH_CLK(1);
         for (uint32_t u = threadIdx.x; u <= last; u += NT) {
             const SuperChain c = follow_to_super(u == last ? nreg : u * kLdsSuperStride, nreg, seg_at, super_of);
             s_sum[u] = c.bytes;
@@ -875,14 +908,17 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
             s_pos[u] = kNoPos;
         }
         __syncthreads();
+        STITCH_CLK(2);
         uint2 whole;
-        const bool chained = order_supers_parallel<NT>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);
+        constexpr int K = (int)((kStitchLdsSupers + NT - 1) / NT);
+        const bool chained = order_supers_parallel<NT, K>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);
         if (threadIdx.x == 0) {
             if (!chained) whole = order_supers(last, s_sum, s_nc, s_pos);
             a.chain[b] = whole;
             a.lens[b] = whole.y < n ? whole.y : n - 1;
         }
         __syncthreads();
+        STITCH_CLK(3);
         for (uint32_t u = threadIdx.x; u <= last; u += NT) {
             uint32_t pos = s_pos[u];
             if (pos == kNoPos) continue;
@@ -897,6 +933,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
             }
         }
         __syncthreads();
+        STITCH_CLK(4);
     }
 }
 
@@ -968,6 +1005,9 @@ constexpr uint32_t kPlaceWindow = 16384;  // bytes of a workgroup's stretch that
 __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
     __shared__ uint32_t s_buf[kPlaceWindow / 4 + 8];  // walk order; 16 bytes of slack for the alignment shift
     __shared__ uint32_t s_p0, s_cut, s_end;
+#ifdef BWT_STITCH_CLOCKS
+    uint64_t clk_ = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t b, k;
     if (!segment_of_lane(a, b, k)) return;  // workgroup-uniform: all lanes of a workgroup serve one block
     const uint32_t n = inv_block_len(a, b);
@@ -990,6 +1030,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
         s_end = 0;
     }
     __syncthreads();
+    STITCH_CLK(5);
     const uint32_t p0 = s_p0;  // walk-order offset of the stretch's first byte (its LAST byte in the text)
     // Walk-order offset o (from p0) <-> text address top - o, top = address of the stretch's last text byte.
     uint8_t* const top = a.out + (uint64_t)b * a.out_stride + (n - 2u) - p0;
@@ -999,6 +1040,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     if (far) atomicMin(&s_cut, pos - p0);
     else if (len) atomicMax(&s_end, pos - p0 + len);
     __syncthreads();
+    STITCH_CLK(6);
     const uint32_t span = min(s_cut, s_end);  // walk-order bytes [0, span) of the stretch go through LDS
     if (far) {
         place_segment_direct(a, b, j, pos, len, n, sb);
@@ -1015,15 +1057,18 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
         uint32_t c = 0, prev = 0;
         const uint32_t last_group = (nd + 1u) >> 2;      // source dwords 0 .. nd+1 are consulted
         uint32_t* const ld = s_buf + ((d0 + head) >> 2);
-        for (uint32_t g = 0; g <= last_group; ++g) {
-            if (g && (g & ((a.slot / 16u) - 1u)) == 0u && 16u * g < len) {  // the next chunk of a long segment
-                c = g == (a.slot / 16u) ? a.seg_ovf[sb + j] : a.chunk_next[pb + c];
-                if (c >= a.chunk_cap) break;  // never
-                src = a.pool + (pb + c) * a.slot;
-                gstride = 16u;
-            }
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + (g & ((a.slot / 16u) - 1u)) * gstride);
+        // The slot's first four groups (every slot has at least four) and the link to the first pool
+        // chunk are loaded at once: fetched one after the other as the copy went along, a workgroup
+        // waited for as many memory round trips in a row as its longest segment has groups.
+        uint4 pre[4];
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) {
+            pre[g] = make_uint4(0u, 0u, 0u, 0u);
+            if (16u * g < len) pre[g] = *reinterpret_cast<const uint4*>(src + g * kStageGroupStride);
+        }
+        uint32_t ovf = 0;
+        if (len > a.slot) ovf = a.seg_ovf[sb + j];
+        auto emit = [&](uint32_t g, const uint4 v) {  // source group g = walk-order bytes 16 g .. 16 g + 15 of the segment
             if (g == 0) {
                 for (uint32_t t = 0; t < head; ++t) lb[d0 + t] = (uint8_t)(v.x >> (8u * t));
             }
@@ -1044,9 +1089,24 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
                 }
             }
             prev = v.w;
+        };
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g)
+            if (g <= last_group) emit(g, pre[g]);
+        for (uint32_t g = 4; g <= last_group; ++g) {
+            if ((g & ((a.slot / 16u) - 1u)) == 0u && 16u * g < len) {  // the next chunk of a long segment
+                c = g == (a.slot / 16u) ? ovf : a.chunk_next[pb + c];
+                if (c >= a.chunk_cap) break;  // never
+                src = a.pool + (pb + c) * a.slot;
+                gstride = 16u;
+            }
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (16u * g < len) v = *reinterpret_cast<const uint4*>(src + (g & ((a.slot / 16u) - 1u)) * gstride);
+            emit(g, v);
         }
     }
     __syncthreads();
+    STITCH_CLK(7);
     // write the stretch out: LDS indices [shift, shift + span) <-> addresses eup - 1 - i.  Group c = indices
     // 16 c .. 16 c + 15 is one aligned 16-byte store, its bytes reversed.
     if (span == 0u) return;
@@ -1066,6 +1126,7 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
             }
         }
     }
+    STITCH_CLK(8);
 }
 
 // ---- origin-pointer blocks: the last step --------------------------------------------------------

@@ -925,7 +925,7 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
         if (g.seg_cap <= kStitchLdsSegs && (g.split_shift == kMinSplitShift || g.nblocks <= (size_t)d.cus))
             hipLaunchKernelGGL(bwt_inverse_stitch_lds_kernel<1024>, dim3((uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus)),
                                dim3(1024), 0, s, a);
-        else if (g.seg_cap > 256u * kSuperStride)  // more super nodes than a 256-thread workgroup orders in parallel
+        else if (g.seg_cap > kStitchSmallSegs)  // more super nodes than the 256-thread kernel's tables hold
             hipLaunchKernelGGL(bwt_inverse_stitch_kernel<1024>, dim3((uint32_t)g.nblocks), dim3(1024), 0, s, a);
         else
             hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
