@@ -1004,44 +1004,52 @@ constexpr uint32_t kPlaceWindow = 16384;  // bytes of a workgroup's stretch that
 
 __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
     __shared__ uint32_t s_buf[kPlaceWindow / 4 + 8];  // walk order; 16 bytes of slack for the alignment shift
-    __shared__ uint32_t s_p0, s_cut, s_end;
+    __shared__ uint32_t s_wend[kSegThreads / kWave];
 #ifdef BWT_STITCH_CLOCKS
     uint64_t clk_ = __builtin_amdgcn_s_memtime();
 #endif
-    uint32_t b, k;
-    if (!segment_of_lane(a, b, k)) return;  // workgroup-uniform: all lanes of a workgroup serve one block
-    const uint32_t n = inv_block_len(a, b);
+    // Everything the workgroup needs to know about its stretch is loaded at once and nothing is
+    // exchanged before the copy: a workgroup's time is memory round trips in a row, and with the
+    // block's mode, its chain, the lane's records and lane 0's position fetched one after the other
+    // and two barriers to pass the latter round there were five of them before the first staged byte.
+    const uint32_t wgs = (a.seg_cap + (uint32_t)kSegThreads - 1u) / (uint32_t)kSegThreads;
+    const uint32_t b = ((blockIdx.x >> 3) / wgs) * 8u + (blockIdx.x & 7u);  // as in segment_of_lane
+    const uint32_t k0 = ((blockIdx.x >> 3) % wgs) * (uint32_t)kSegThreads;  // the workgroup's first segment on the chain
+    const uint32_t k = k0 + threadIdx.x;
+    if (b >= a.nblocks || k0 >= a.seg_cap) return;  // workgroup-uniform
     const uint64_t sb = (uint64_t)b * a.seg_cap;
+    const uint32_t mode = a.mode[b];
     const uint2 whole = a.chain[b];
-    const uint32_t k0 = k - threadIdx.x;  // the workgroup's first segment on the chain
-    if (k0 >= whole.x || k0 >= a.seg_cap) return;  // workgroup-uniform: segments off the chain have no place
+    const uint32_t p0 = a.seg_rec[sb + k0].y;  // walk-order offset of the stretch's first byte (its LAST byte in the text)
+    uint2 rec = make_uint2(0u, 0u);
+    uint32_t pos1 = 0;
+    if (k < a.seg_cap) rec = a.seg_rec[sb + k];
+    if (k + 1u < a.seg_cap) pos1 = a.seg_rec[sb + k + 1u].y;
+    if (mode != kModeMulti || k0 >= whole.x) return;  // workgroup-uniform: segments off the chain have no place
+    const uint32_t n = inv_block_len(a, b);
     const bool mine = k < whole.x && k < a.seg_cap;
-    uint32_t j = 0, pos = 0, len = 0;
+    uint32_t j = 0, pos = p0, len = 0;
     if (mine) {
-        const uint2 rec = a.seg_rec[sb + k];
         j = rec.x;
         pos = rec.y;
-        len = (k + 1u < whole.x ? a.seg_rec[sb + k + 1u].y : whole.y) - pos;
-        if ((uint64_t)pos + len > (uint64_t)(n - 1)) len = 0;  // never: the chain is at most n-1 bytes long
+        len = (k + 1u < whole.x ? pos1 : whole.y) - pos;
+        if ((uint64_t)pos + len > (uint64_t)(n - 1) || pos < p0) len = 0;  // never: the chain is at most n-1 bytes long
     }
-    if (threadIdx.x == 0) {
-        s_p0 = pos;
-        s_cut = 0xFFFFFFFFu;
-        s_end = 0;
-    }
-    __syncthreads();
     STITCH_CLK(5);
-    const uint32_t p0 = s_p0;  // walk-order offset of the stretch's first byte (its LAST byte in the text)
     // Walk-order offset o (from p0) <-> text address top - o, top = address of the stretch's last text byte.
     uint8_t* const top = a.out + (uint64_t)b * a.out_stride + (n - 2u) - p0;
     const uint32_t shift = (uint32_t)((16u - ((uint32_t)reinterpret_cast<uintptr_t>(top + 1) & 15u)) & 15u);  // LDS index = o + shift
     uint8_t* const eup = top + 1 + shift;  // 16-byte aligned: LDS index i <-> address eup - 1 - i
     const bool far = mine && (pos - p0) + len > kPlaceWindow;  // reaches beyond the window: written directly
-    if (far) atomicMin(&s_cut, pos - p0);
-    else if (len) atomicMax(&s_end, pos - p0 + len);
-    __syncthreads();
+    {
+        // walk-order bytes [0, span) of the stretch go through LDS: up to the end of the last segment that
+        // fits the window (positions grow with k, so the segments that do not fit are the last ones)
+        uint32_t wend = (!far && len) ? pos - p0 + len : 0u;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) wend = max(wend, (uint32_t)__shfl_xor((int)wend, o));
+        if ((threadIdx.x & (kWave - 1)) == 0) s_wend[threadIdx.x / kWave] = wend;
+    }
     STITCH_CLK(6);
-    const uint32_t span = min(s_cut, s_end);  // walk-order bytes [0, span) of the stretch go through LDS
     if (far) {
         place_segment_direct(a, b, j, pos, len, n, sb);
     } else if (len) {
@@ -1107,6 +1115,9 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     }
     __syncthreads();
     STITCH_CLK(7);
+    uint32_t span = 0;
+#pragma unroll
+    for (int w = 0; w < kSegThreads / kWave; ++w) span = max(span, s_wend[w]);
     // write the stretch out: LDS indices [shift, shift + span) <-> addresses eup - 1 - i.  Group c = indices
     // 16 c .. 16 c + 15 is one aligned 16-byte store, its bytes reversed.
     if (span == 0u) return;
