@@ -65,14 +65,35 @@ __device__ __forceinline__ uint64_t match_digit_bits(uint32_t d, bool valid, int
 // matters).
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 
-// Inclusive prefix sum across the 64 lanes of a wave.
+// Loads and stores through a pointer that is known to point to device memory.  Inside a function
+// that is not inlined into its kernel the compiler cannot tell, and a generic access is a FLAT
+// instruction, which counts as an LDS operation as well: every wait for an LDS result then also
+// waits for all such loads in flight, and loads issued ahead for the next tile hide nothing.
+template <typename T>
+__device__ __forceinline__ T load_global(const T* p) {
+    return *(const __attribute__((address_space(1))) T*)p;
+}
+template <typename T>
+__device__ __forceinline__ void store_global(T* p, T v) {
+    *(__attribute__((address_space(1))) T*)p = v;
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave (all of them active).  Six adds whose second
+// operand comes through the data-parallel primitives of the vector ALU: inside each row of 16 lanes
+// from 1, 2, 4 and 8 lanes below (a lane with nothing below it adds 0), then lane 15 of rows 0 and 2
+// to the rows above them and lane 31 to rows 2 and 3.  (Through __shfl_up every step is an LDS
+// crossbar instruction and a wait for it: a scan was 6 dependent LDS round trips.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t y = __shfl_up(v, o);
-        if (lane >= o) v += y;
-    }
+    v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -82,12 +103,7 @@ template <int NT>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wsum, uint32_t& total) {
     constexpr int W = NT / kWave;
     const int lane = lane_id(), w = wave_id();
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
+    const uint32_t x = wave_inclusive_scan(v);
     if (lane == kWave - 1) s_wsum[w] = x;
     __syncthreads();
     uint32_t pre = 0, tot = 0;

@@ -35,6 +35,9 @@
 // buffers, one u32 rank array, a small bucket directory); LDS holds the staging tiles, the
 // bucket being sorted and the counters.
 #pragma once
+#ifndef BWT_NOINLINE_SORT
+#define BWT_NOINLINE_SORT 0
+#endif
 #include <type_traits>
 
 #include "bwt_device.hpp"
@@ -136,6 +139,7 @@ struct FwdShared {
     uint32_t hist[2][W * kBins];    // per-wave digit counts / scatter offsets, double buffered
     uint8_t sym[256];               // byte value -> code
     uint32_t wsum[W];
+    uint32_t wsum2[2][W];  // the in-LDS sort alternates between the two (one barrier less per pass)
     uint32_t cntA[W], cntG[W], lastH[W], lastG[W];
     uint32_t chunk_bad;             // a doubling round's survivors cannot be cut into LDS-sized chunks of whole groups
     unsigned long long vote;        // periodic runs: members << 32 | step of the most populous long step
@@ -371,8 +375,18 @@ __device__ __forceinline__ void count_digits(const uint64_t* __restrict__ src, u
 // real elements, so stability keeps it behind them.
 // While in LDS an element is kept shifted left so that its sort key ends at bit 63: when the
 // key has at most 32 bits (NARROW) every digit is a bit field of the high dword.
+#if BWT_NOINLINE_SORT == 2
+#define BWT_SORT_PASSES_INLINE __noinline__
+#else
+#define BWT_SORT_PASSES_INLINE __forceinline__
+#endif
+#if BWT_NOINLINE_SORT == 1
+#define BWT_SORT_BUCKET_INLINE __noinline__
+#else
+#define BWT_SORT_BUCKET_INLINE __forceinline__
+#endif
 template <int NT, bool NARROW>
-__device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up, FwdShared<NT>& sh) {
+__device__ BWT_SORT_PASSES_INLINE void lds_sort_passes(uint32_t nthr, int bits, int up, FwdShared<NT>& sh) {
     constexpr int V = FwdCfg<NT>::kSortVecs;
     const int tid = threadIdx.x;
     const bool active = (uint32_t)tid < nthr;
@@ -398,13 +412,16 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
         __syncthreads();  // counters cleared, previous pass (or the staging) landed in ls
         uint64_t e[V];
         uint32_t old[V];
+        uint32_t cwi[V], half[V];  // counter word of the element's digit and which half of it (0 / 16): kept for the scatter
         if (active) {
 #pragma unroll
             for (int j = 0; j < V; ++j) e[j] = mine[j];
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const uint32_t d = digit(e[j], o);
-                old[j] = atomicAdd(&mycw[(d & 7u) * RS], 1u << ((d << 1) & 16u));
+                cwi[j] = (d & 7u) * RS;
+                half[j] = (d << 1) & 16u;
+                old[j] = atomicAdd(&mycw[cwi[j]], 1u << half[j]);
             }
         }
         __syncthreads();
@@ -416,8 +433,21 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
                 c[i] = scan8[i];
                 sum += c[i];
             }
-            uint32_t total;
-            uint32_t run = block_exclusive_scan<NT>(sum, sh.wsum, total);
+            // exclusive scan over the workgroup; the wave sums of consecutive passes go to alternate
+            // buffers, so nobody has to wait until everybody has read them
+            constexpr int W = NT / kWave;
+            uint32_t* ws = sh.wsum2[p & 1];
+            const uint32_t incl = wave_inclusive_scan(sum);
+            if (lane_id() == kWave - 1) ws[wave_id()] = incl;
+            __syncthreads();
+            uint32_t pre = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint32_t t = ws[i];
+                if (i < wave_id()) pre += t;
+                total += t;
+            }
+            uint32_t run = pre + incl - sum;
             run += (total & 0xFFFFu) << 16;  // every digit >= 8 comes after all digits < 8
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -429,13 +459,10 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
         if (active) {
             uint32_t off[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) off[j] = mycw[(digit(e[j], o) & 7u) * RS];
+            for (int j = 0; j < V; ++j) off[j] = mycw[cwi[j]];
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                // run start and my rank inside it sit in the same half of their words
-                const uint32_t hs = (digit(e[j], o) << 1) & 16u;
-                ls[__builtin_amdgcn_ubfe(off[j] + old[j], hs, 16u)] = e[j];
-            }
+            for (int j = 0; j < V; ++j)  // run start and my rank inside it sit in the same half of their words
+                ls[__builtin_amdgcn_ubfe(off[j] + old[j], half[j], 16u)] = e[j];
         }
     }
     __syncthreads();
@@ -443,7 +470,7 @@ __device__ __forceinline__ void lds_sort_passes(uint32_t nthr, int bits, int up,
 }
 
 template <int NT>
-__device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, uint32_t cnt, int kshift,
+__device__ BWT_SORT_BUCKET_INLINE void lds_sort_bucket(const uint64_t* __restrict__ g, uint32_t cnt, int kshift,
                                                 uint64_t base, int bits, FwdShared<NT>& sh, int& up,
                                                 uint64_t& bsub) {
     constexpr int V = FwdCfg<NT>::kSortVecs;
@@ -463,7 +490,7 @@ __device__ __forceinline__ void lds_sort_bucket(const uint64_t* __restrict__ g, 
     for (uint32_t i0 = tid; i0 < cntp; i0 += 8 * NT) {  // eight loads in flight per thread
         uint64_t x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = g[min(i0 + (uint32_t)(u * NT), cnt - 1u)];
+        for (int u = 0; u < 8; ++u) x[u] = load_global(g + min(i0 + (uint32_t)(u * NT), cnt - 1u));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const uint32_t i = i0 + (uint32_t)(u * NT);
@@ -649,11 +676,11 @@ __device__ __forceinline__ uint32_t tail_order(const Round0& r, uint32_t idx) {
 }
 
 __device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t* p, const uint8_t* g_lo, const uint8_t* g_hi) {
-    if (p >= g_lo && p + 4 <= g_hi) return *reinterpret_cast<const uint32_t*>(p);
+    if (p >= g_lo && p + 4 <= g_hi) return load_global(reinterpret_cast<const uint32_t*>(p));
     uint32_t v = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (p + j >= g_lo && p + j < g_hi) v |= (uint32_t)p[j] << (8 * j);
+        if (p + j >= g_lo && p + j < g_hi) v |= (uint32_t)load_global(p + j) << (8 * j);
     return v;
 }
 
@@ -807,7 +834,7 @@ __device__ __noinline__ void round0_sweep(const Round0 r, const BucketDigit dig,
 #pragma unroll
             for (int u = 0; u < kRun; ++u) {
                 if ((uint32_t)(u * kWave + lane) < total) {
-                    if (pos[u] < r.n) dst[pos[u]] = x[u];
+                    if (pos[u] < r.n) store_global(dst + pos[u], x[u]);
                     else bad = true;  // unreachable unless the histogram is inconsistent
                 }
             }
@@ -820,6 +847,99 @@ __device__ __noinline__ void round0_sweep(const Round0 r, const BucketDigit dig,
             }
             compiler_fence();
         }
+    }
+}
+
+// Second step of the round-0 partition of a block with more than kBins buckets.  The sweep has
+// grouped the elements by the high part of their bucket id; the elements [lo, hi) of one such group
+// in src are partitioned here by the low part (`dig`) into dst, the waves sharing one cursor per
+// digit in hist[sel] (absolute positions in dst, set by the caller).  The same tile partition as
+// in round0_sweep: no order is kept inside a bucket, the elements take their slots from LDS
+// counters, the tile is laid out grouped by digit and leaves in runs.
+template <int NT>
+__device__ __forceinline__ void partition_group(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t lo,
+                                             uint32_t hi, uint32_t n, const BucketDigit dig, FwdShared<NT>& sh, int sel,
+                                             uint32_t* err) {
+    constexpr int W = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    uint32_t chunk = (hi - lo + (uint32_t)W - 1u) / (uint32_t)W;
+    chunk = (chunk + (uint32_t)kTile - 1u) / (uint32_t)kTile * (uint32_t)kTile;
+    const uint32_t wlo = min(lo + (uint32_t)w * chunk, hi), whi = min(wlo + chunk, hi);
+    uint32_t* tcnt = sh.u.st.tcnt[w];
+    uint32_t* tdel = sh.u.st.tdel[w];
+    uint64_t* tin = sh.u.st.tin[w];
+    uint64_t nel[kRun];
+    auto fetch = [&](uint32_t tile) {
+#pragma unroll
+        for (int u = 0; u < kRun; ++u) {
+            const uint32_t q = tile + (uint32_t)(u * kWave + lane);
+            nel[u] = q < whi ? load_global(src + q) : 0ull;
+        }
+    };
+    if (wlo < whi) fetch(wlo);
+    for (uint32_t tile = wlo; tile < whi; tile += kTile) {
+        uint64_t el[kRun];
+        uint32_t valid_bits = 0;
+#pragma unroll
+        for (int u = 0; u < kRun; ++u) {
+            el[u] = nel[u];
+            if (tile + (uint32_t)(u * kWave + lane) < whi) valid_bits |= 1u << u;
+        }
+        if (tile + kTile < whi) fetch(tile + kTile);  // the next tile's loads fly while this one is processed
+        tcnt[lane] = 0;
+        compiler_fence();
+        uint32_t dj[kRun], rk[kRun];
+#pragma unroll
+        for (int j = 0; j < kRun; ++j) {
+            dj[j] = dig(el[j]);
+            rk[j] = 0;
+            if ((valid_bits >> j) & 1u) rk[j] = atomicAdd(&tcnt[dj[j]], 1u);
+        }
+        compiler_fence();
+        const uint32_t c = tcnt[lane];
+        const uint32_t incl = wave_inclusive_scan(c);
+        const uint32_t excl = incl - c;
+        const uint32_t total = __shfl(incl, kWave - 1);
+        const uint32_t g0 = c ? atomicAdd(&sh.hist[sel][lane], c) : 0u;
+        compiler_fence();
+        tcnt[lane] = excl;
+        tdel[lane] = g0 - excl;
+        compiler_fence();
+#pragma unroll
+        for (int j = 0; j < kRun; ++j)
+            if ((valid_bits >> j) & 1u) tin[tcnt[dj[j]] + rk[j]] = el[j];
+        compiler_fence();
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < kRun; ++u) {
+            const uint32_t slot = (uint32_t)(u * kWave + lane);
+            if (slot < total) {  // slots past `total` hold stale data
+                const uint64_t x = tin[slot];
+                const uint32_t pos = tdel[dig(x)] + slot;
+                if (pos < n) store_global(dst + pos, x);
+                else bad = true;  // unreachable unless the directory is inconsistent
+            }
+        }
+        if (bad) atomicOr(err, kErrBounds);
+        compiler_fence();
+    }
+}
+
+// All groups of 2^low_bits buckets, one after the other; start[k] = first slot of bucket k (start[nb] = n).
+// Every thread of the workgroup must call.
+template <int NT>
+__device__ __noinline__ void partition_groups(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                                              const uint32_t* start, uint32_t nb, int low_bits, uint32_t n,
+                                              const BucketDigit dig, FwdShared<NT>& sh, uint32_t* err) {
+    const int lane = lane_id(), w = wave_id();
+    const uint32_t groups = (nb + (1u << low_bits) - 1u) >> low_bits;
+#pragma unroll 1
+    for (uint32_t gq = 0; gq < groups; ++gq) {
+        const uint32_t k0 = gq << low_bits;
+        if (w == 0) sh.hist[0][lane] = start[min(k0 + (uint32_t)lane, nb)];
+        __syncthreads();
+        partition_group<NT>(src, dst, start[k0], start[min(k0 + (1u << low_bits), nb)], n, dig, sh, 0, err);
+        __syncthreads();
     }
 }
 
@@ -2569,6 +2689,7 @@ restart:
         put_off();
         return;
     }
+#ifdef BWT_OLD_TWO_PASS
     const bool two_pass = dir.nb > (uint32_t)kBins;
     const int b1 = two_pass ? 4 : kMaxDigitBits;
     dig.mask = (1u << b1) - 1u;
@@ -2600,6 +2721,35 @@ restart:
         sorted0 = bufB;
         spare = bufA;
     }
+#else
+    // More than kBins buckets (blocks above 256 KiB): the sweep groups the elements by the high part
+    // of the bucket id (groups of 16 buckets), and every group is then partitioned by the low 4 bits.
+    const bool two_pass = dir.nb > (uint32_t)kBins;
+    constexpr int kLowBits = 4;
+    if (two_pass) {
+        dig.shift = kLowBits;
+        dig.mask = (1u << kMaxDigitBits) - 1u;
+        dig2.mask = (1u << kLowBits) - 1u;
+    } else {
+        dig.mask = (1u << kMaxDigitBits) - 1u;
+    }
+    // shared cursors of the partition pass: where each digit's elements start
+    zero_hist<NT>(sh, 1);
+    if (w == 0) {
+        const uint32_t first = two_pass ? (uint32_t)lane << kLowBits : (uint32_t)lane;
+        sh.hist[0][lane] = dir.start[min(first, dir.nb)];
+    }
+    __syncthreads();
+    round0_sweep<NT, 1>(r0, dig, dig2, false, bufA, sh, 0, &queue[1]);
+    __syncthreads();
+    uint64_t* sorted0 = bufA;
+    uint64_t* spare = bufB;
+    if (two_pass) {
+        partition_groups<NT>(bufA, bufB, dir.start, dir.nb, kLowBits, n, dig2, sh, &queue[1]);
+        sorted0 = bufB;
+        spare = bufA;
+    }
+#endif
     pc.lap(2);
     // element layout for rounds >= 1: g | r2 | i, where r2 = rank[i+h] + 1, or 0 when the
     // suffix ends exactly at i+h (possible only if the delimiter also occurs inside the

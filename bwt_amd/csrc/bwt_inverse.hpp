@@ -77,7 +77,10 @@ constexpr uint32_t kMinSplitShift = 4;       // rows between regular splitters: 
 constexpr uint32_t kMultiMinRows = 4096;     // shorter blocks are walked as one chain when the batch has many blocks
 constexpr uint32_t kMultiMinRowsFew = 1280;  // ... and this is the bound when it has few: the chains are the whole cost then
 constexpr uint32_t kFewBlocks = 2048;
-constexpr int kSegThreads = 256;             // workgroup size of the segment kernels
+#ifndef BWT_SEG_THREADS
+#define BWT_SEG_THREADS 128
+#endif
+constexpr int kSegThreads = BWT_SEG_THREADS;  // workgroup size of the place kernel
                                              // staging slot per segment = 4 x that many bytes (InvArgs::slot)
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 constexpr uint32_t kModeMulti = 0, kModeSingle = 1, kModeNone = 2;
@@ -1000,7 +1003,7 @@ __device__ __forceinline__ void place_segment_direct(const InvArgs& a, uint32_t 
     bw.flush();
 }
 
-constexpr uint32_t kPlaceWindow = 16384;  // bytes of a workgroup's stretch that are assembled in LDS
+constexpr uint32_t kPlaceWindow = 64u * kSegThreads;  // bytes of a workgroup's stretch that are assembled in LDS
 
 __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
     __shared__ uint32_t s_buf[kPlaceWindow / 4 + 8];  // walk order; 16 bytes of slack for the alignment shift
