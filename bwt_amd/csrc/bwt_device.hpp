@@ -87,6 +87,13 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
+// The value of the lane below (lane 0: `first`) / above (lane 63: `last`), all 64 lanes active.
+__device__ __forceinline__ uint32_t wave_from_below(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false);  // wave_shr:1
+}
+__device__ __forceinline__ uint32_t wave_from_above(uint32_t v, uint32_t last) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xF, 0xF, false);  // wave_shl:1
+}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
     v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2

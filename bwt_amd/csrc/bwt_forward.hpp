@@ -1238,22 +1238,37 @@ __device__ __forceinline__ void rerank_bucket(uint64_t* __restrict__ g, uint32_t
         uint32_t v = 0;
         for (uint32_t base = lo; base < hi; base += U * kWave, v += U) {
             uint64_t key[U], kp[U], kn[U], y[U];
+            if (ks >= 32) {  // the key fits the high dword
+                // one read per element; the neighbours' keys come from the neighbouring lanes, and only
+                // the element before the first and after the last of the U vectors from LDS
+                const uint32_t* hi32 = reinterpret_cast<const uint32_t*>(ls) + 1;
+                const int sh32 = ks - 32;
+                uint32_t k32[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {  // clamped indices: every read is in range, the flags below sort out validity
-                const uint32_t k = base + (uint32_t)(u * kWave + lane);
-                const uint32_t kc = min(k, kmax), kl = min(k - 1u, kmax), kr = min(k + 1u, kmax);
-                if (ks >= 32) {  // the key fits the high dword: 4-byte LDS reads
-                    const uint32_t* hi32 = reinterpret_cast<const uint32_t*>(ls) + 1;
-                    const int sh32 = ks - 32;
+                for (int u = 0; u < U; ++u) {  // clamped indices: every read is in range, the flags below sort out validity
+                    const uint32_t kc = min(base + (uint32_t)(u * kWave + lane), kmax);
                     if (fast) {
                         y[u] = ls[kc];
-                        key[u] = (uint32_t)(y[u] >> 32) >> sh32;
+                        k32[u] = (uint32_t)(y[u] >> 32) >> sh32;
                     } else {
-                        key[u] = hi32[2 * kc] >> sh32;
+                        k32[u] = hi32[2 * kc] >> sh32;
                     }
-                    kp[u] = hi32[2 * kl] >> sh32;
-                    kn[u] = hi32[2 * kr] >> sh32;
-                } else {
+                }
+                const uint32_t before = hi32[2 * min(base - 1u, kmax)] >> sh32;
+                const uint32_t after = hi32[2 * min(base + (uint32_t)(U * kWave), kmax)] >> sh32;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t first = u == 0 ? before : (uint32_t)__builtin_amdgcn_readlane((int)k32[u == 0 ? 0 : u - 1], kWave - 1);
+                    const uint32_t last = u == U - 1 ? after : (uint32_t)__builtin_amdgcn_readfirstlane((int)k32[u == U - 1 ? u : u + 1]);
+                    key[u] = k32[u];
+                    kp[u] = wave_from_below(k32[u], first);
+                    kn[u] = wave_from_above(k32[u], last);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t k = base + (uint32_t)(u * kWave + lane);
+                    const uint32_t kc = min(k, kmax), kl = min(k - 1u, kmax), kr = min(k + 1u, kmax);
                     y[u] = ls[kc];
                     key[u] = y[u] >> ks;
                     kp[u] = ls[kl] >> ks;

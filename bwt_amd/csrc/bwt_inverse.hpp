@@ -727,12 +727,13 @@ __device__ __forceinline__ uint2 order_supers(uint32_t last, uint32_t* s_sum, ui
 // form ONE chain from the delimiter's node through all of them: log2 rounds of pointer jumping give
 // every node the bytes, segments and nodes from itself to the chain's end, and what lies before a node
 // is the total minus that.  (One thread following some 500 links, each a dependent LDS access, was
-// half the stitch kernel's time.)  Returns false, with the arrays as they were, when the nodes do not
-// form such a chain (hand-made blocks); the caller then orders them with order_supers.
-// s_nxt / s_hops: scratch of last + 1 words each.  All threads of the workgroup must call.
+// half the stitch kernel's time.)  Works in the three arrays themselves -- s_sum: bytes, s_pos:
+// segments << 13 | nodes, s_nc: next node -- so a false return (the nodes do not form such a chain:
+// hand-made blocks) leaves them overwritten: the caller fills them again and orders the nodes with
+// order_supers.  All threads of the workgroup must call.
 template <int NT, int K = 1>  // K: super nodes per thread (node u belongs to thread u % NT)
 __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s_sum, uint32_t* s_nc, uint32_t* s_pos,
-                                                      uint32_t* s_nxt, uint32_t* s_hops, uint2* whole) {
+                                                      uint2* whole) {
     if (last + 1u > (uint32_t)(NT * K) || last + 1u >= 8192u) return false;  // workgroup-uniform
     uint32_t bytes[K], segs[K], hops[K], nx[K];
     bool mine[K];
@@ -748,9 +749,8 @@ __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s
             segs[k] = s_nc[u] >> 13;
             nx[k] = s_nc[u] & kSuperNone;
             if (nx[k] == last) nx[k] = kSuperNone;  // back at the delimiter row: the text is complete
-            s_pos[u] = bytes[k];
-            s_hops[u] = (segs[k] << 13) | 1u;       // segments (at most 2^17 per block) above the node count (below 2^13)
-            s_nxt[u] = nx[k];
+            s_pos[u] = (segs[k] << 13) | 1u;        // segments (at most 2^17 per block) above the node count (below 2^13)
+            s_nc[u] = nx[k];
         }
     }
     __syncthreads();
@@ -761,9 +761,9 @@ __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s
             b2[k] = h2[k] = 0;
             n2[k] = kSuperNone;
             if (mine[k] && nx[k] != kSuperNone) {
-                b2[k] = s_pos[nx[k]];
-                h2[k] = s_hops[nx[k]];
-                n2[k] = s_nxt[nx[k]];
+                b2[k] = s_sum[nx[k]];
+                h2[k] = s_pos[nx[k]];
+                n2[k] = s_nc[nx[k]];
             }
         }
         __syncthreads();
@@ -775,9 +775,9 @@ __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s
                 segs[k] += h2[k] >> 13;
                 hops[k] += h2[k] & 8191u;
                 nx[k] = n2[k];
-                s_pos[u] = bytes[k];
-                s_hops[u] = (segs[k] << 13) | (hops[k] & 8191u);
-                s_nxt[u] = nx[k];
+                s_sum[u] = bytes[k];
+                s_pos[u] = (segs[k] << 13) | (hops[k] & 8191u);
+                s_nc[u] = nx[k];
             }
         }
         __syncthreads();
@@ -786,17 +786,11 @@ __device__ __forceinline__ bool order_supers_parallel(uint32_t last, uint32_t* s
     bool done = true;
 #pragma unroll
     for (int k = 0; k < K; ++k) done = done && (!mine[k] || nx[k] == kSuperNone);
-    const uint32_t head_hops = s_hops[last] & 8191u;
+    const uint32_t head_hops = s_pos[last] & 8191u;
     const bool ok = __syncthreads_and(done) && head_hops == last + 1u;
-    const uint32_t tot_bytes = s_pos[last], tot_segs = s_hops[last] >> 13;
+    const uint32_t tot_bytes = s_sum[last], tot_segs = s_pos[last] >> 13;
     __syncthreads();
-    if (!ok) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (mine[k]) s_pos[threadIdx.x + (uint32_t)(k * NT)] = kNoPos;  // as the caller left it
-        __syncthreads();
-        return false;
-    }
+    if (!ok) return false;
 #pragma unroll
     for (int k = 0; k < K; ++k)
         if (mine[k]) {
@@ -816,7 +810,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
     constexpr uint32_t kSupers = NT >= 1024 ? kMaxSegments / 32u + 2u : (kStitchSmallSegs >> kMinSuperShift) + 2u;
     constexpr int K = (int)((kSupers + NT - 1) / NT);  // super nodes per thread in the parallel ordering
     static_assert(kSupers < kSuperNone, "next super node in 13 bits");
-    __shared__ uint32_t s_sum[kSupers], s_nc[kSupers], s_pos[kSupers], s_nxt[kSupers], s_hops[kSupers];
+    __shared__ uint32_t s_sum[kSupers], s_nc[kSupers], s_pos[kSupers];
     const uint32_t b = blockIdx.x;
     if (a.mode[b] != kModeMulti) return;  // workgroup-uniform
     const uint32_t n = inv_block_len(a, b);
@@ -829,15 +823,19 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
         return (id & smask) == 0u ? id >> sshift : kNoPos;
     };
     auto seg_at = [&](uint32_t id) { return a.seg[sb + id]; };
-    for (uint32_t u = threadIdx.x; u <= last; u += NT) {
-        const SuperChain c = follow_to_super(u == last ? nreg : u << sshift, nreg, seg_at, super_of);
-        s_sum[u] = c.bytes;
-        s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
-        s_pos[u] = kNoPos;
-    }
-    __syncthreads();
+    auto sum_chains = [&]() {
+        for (uint32_t u = threadIdx.x; u <= last; u += NT) {
+            const SuperChain c = follow_to_super(u == last ? nreg : u << sshift, nreg, seg_at, super_of);
+            s_sum[u] = c.bytes;
+            s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
+            s_pos[u] = kNoPos;
+        }
+        __syncthreads();
+    };
+    sum_chains();
     uint2 whole;
-    const bool chained = order_supers_parallel<NT, K>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);  // blocks of up to NT * K super nodes
+    const bool chained = order_supers_parallel<NT, K>(last, s_sum, s_nc, s_pos, &whole);  // blocks of up to NT * K super nodes
+    if (!chained) sum_chains();  // workgroup-uniform
     if (threadIdx.x == 0) {
         if (!chained) whole = order_supers(last, s_sum, s_nc, s_pos);
         a.chain[b] = whole;
@@ -863,7 +861,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_kernel(InvArgs a) {
 // global memory is one random 64-byte transaction per segment and phase, in LDS it is a few
 // cycles.  For blocks of at most kStitchLdsSegs segments; one workgroup per CU.
 constexpr uint32_t kStitchLdsSegs = 16640;
-constexpr uint32_t kLdsSuperStride = 16;  // stride 8 would need 42 KB of tables beside the 133 KB of records
+constexpr uint32_t kLdsSuperStride = 16;  // measured: 8 is slower (three nodes per thread in every round of the ordering), 32 too (longer chains)
 constexpr uint32_t kStitchLdsSupers = kStitchLdsSegs / kLdsSuperStride + 2u;
 
 // Debug builds (-DBWT_STITCH_CLOCKS) add up thread 0's clock over the kernel's steps in the workspace
@@ -888,7 +886,6 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
 #endif
     __shared__ uint2 s_seg[kStitchLdsSegs];
     __shared__ uint32_t s_sum[kStitchLdsSupers], s_nc[kStitchLdsSupers], s_pos[kStitchLdsSupers];
-    __shared__ uint32_t s_nxt[kStitchLdsSupers], s_hops[kStitchLdsSupers];
     for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
         if (a.mode[b] != kModeMulti) continue;  // workgroup-uniform
         const uint32_t n = inv_block_len(a, b);
@@ -904,17 +901,21 @@ __global__ __launch_bounds__(NT) void bwt_inverse_stitch_lds_kernel(InvArgs a) {
         for (uint32_t i = threadIdx.x; i <= nreg; i += NT) s_seg[i] = a.seg[sb + i];
         __syncthreads();
         STITCH_CLK(1);
-        for (uint32_t u = threadIdx.x; u <= last; u += NT) {
-            const SuperChain c = follow_to_super(u == last ? nreg : u * kLdsSuperStride, nreg, seg_at, super_of);
-            s_sum[u] = c.bytes;
-            s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
-            s_pos[u] = kNoPos;
-        }
-        __syncthreads();
+        auto sum_chains = [&]() {
+            for (uint32_t u = threadIdx.x; u <= last; u += NT) {
+                const SuperChain c = follow_to_super(u == last ? nreg : u * kLdsSuperStride, nreg, seg_at, super_of);
+                s_sum[u] = c.bytes;
+                s_nc[u] = (c.segments << 13) | (c.next == kNoPos ? kSuperNone : c.next);
+                s_pos[u] = kNoPos;
+            }
+            __syncthreads();
+        };
+        sum_chains();
         STITCH_CLK(2);
         uint2 whole;
         constexpr int K = (int)((kStitchLdsSupers + NT - 1) / NT);
-        const bool chained = order_supers_parallel<NT, K>(last, s_sum, s_nc, s_pos, s_nxt, s_hops, &whole);
+        const bool chained = order_supers_parallel<NT, K>(last, s_sum, s_nc, s_pos, &whole);
+        if (!chained) sum_chains();  // workgroup-uniform
         if (threadIdx.x == 0) {
             if (!chained) whole = order_supers(last, s_sum, s_nc, s_pos);
             a.chain[b] = whole;
