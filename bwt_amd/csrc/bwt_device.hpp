@@ -87,12 +87,28 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
+// The value one lane holds, for all lanes (`src` is the same in all of them): a read of the register
+// through the scalar unit instead of __shfl's trip through the LDS crossbar.
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+}
+__device__ __forceinline__ uint64_t wave_read(uint64_t v, int src) {
+    return ((uint64_t)wave_read((uint32_t)(v >> 32), src) << 32) | wave_read((uint32_t)v, src);
+}
 // The value of the lane below (lane 0: `first`) / above (lane 63: `last`), all 64 lanes active.
 __device__ __forceinline__ uint32_t wave_from_below(uint32_t v, uint32_t first) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false);  // wave_shr:1
 }
 __device__ __forceinline__ uint32_t wave_from_above(uint32_t v, uint32_t last) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xF, 0xF, false);  // wave_shl:1
+}
+__device__ __forceinline__ uint64_t wave_from_below(uint64_t v, uint64_t first) {
+    return ((uint64_t)wave_from_below((uint32_t)(v >> 32), (uint32_t)(first >> 32)) << 32) |
+           wave_from_below((uint32_t)v, (uint32_t)first);
+}
+__device__ __forceinline__ uint64_t wave_from_above(uint64_t v, uint64_t last) {
+    return ((uint64_t)wave_from_above((uint32_t)(v >> 32), (uint32_t)(last >> 32)) << 32) |
+           wave_from_above((uint32_t)v, (uint32_t)last);
 }
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1

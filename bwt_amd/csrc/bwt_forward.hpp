@@ -251,7 +251,7 @@ __device__ __forceinline__ void scatter_staged(int nvec, ValidOf valid_of, Digit
     const uint32_t c = tcnt[lane];
     const uint32_t incl = wave_inclusive_scan(c);
     const uint32_t excl = incl - c;
-    const uint32_t total = __shfl(incl, kWave - 1);
+    const uint32_t total = wave_read(incl, kWave - 1);
     uint32_t g0;
     if (SHARED_CURSORS) {
         g0 = c ? atomicAdd(&myoff[lane], c) : 0u;
@@ -609,9 +609,9 @@ __device__ __noinline__ bool settle_dominant_key(uint64_t* __restrict__ a, uint3
             if (MV) b_mv = atomicAdd(&sh.cntA[1], (uint32_t)__popcll(MV));
             if (HO) b_ho = atomicAdd(&sh.cntA[2], (uint32_t)__popcll(HO));
         }
-        b_ne = __shfl(b_ne, 0);
-        b_mv = __shfl(b_mv, 0);
-        b_ho = __shfl(b_ho, 0);
+        b_ne = wave_read(b_ne, 0);
+        b_mv = wave_read(b_mv, 0);
+        b_ho = wave_read(b_ho, 0);
         if (ne) {
             const uint32_t i = b_ne + (uint32_t)__popcll(NE & lt);
             s_ne[i] = e;
@@ -811,7 +811,7 @@ __device__ __noinline__ void round0_sweep(const Round0 r, const BucketDigit dig,
             const uint32_t c = tcnt[lane];
             const uint32_t incl = wave_inclusive_scan(c);
             const uint32_t excl = incl - c;
-            const uint32_t total = __shfl(incl, kWave - 1);
+            const uint32_t total = wave_read(incl, kWave - 1);
             const uint32_t g0 = c ? atomicAdd(&sh.hist[sel][lane], c) : 0u;
             compiler_fence();
             tcnt[lane] = excl;
@@ -899,7 +899,7 @@ __device__ __forceinline__ void partition_group(const uint64_t* __restrict__ src
         const uint32_t c = tcnt[lane];
         const uint32_t incl = wave_inclusive_scan(c);
         const uint32_t excl = incl - c;
-        const uint32_t total = __shfl(incl, kWave - 1);
+        const uint32_t total = wave_read(incl, kWave - 1);
         const uint32_t g0 = c ? atomicAdd(&sh.hist[sel][lane], c) : 0u;
         compiler_fence();
         tcnt[lane] = excl;
@@ -1011,8 +1011,8 @@ __device__ __forceinline__ void assign_buckets(FwdShared<NT>& sh, uint32_t n, ui
                 dir.start[k] = sv;
                 dir.flo[k] = fv;
             }
-            cs = __shfl(sv, 0);
-            cf = __shfl(fv, 0);
+            cs = wave_read(sv, 0);
+            cf = wave_read(fv, 0);
         }
     }
     __syncthreads();
@@ -1047,12 +1047,10 @@ __device__ __forceinline__ void for_each_run_vector(const uint64_t* __restrict__
             if (vb < hi) {  // wave-uniform
                 const uint32_t k = vb + lane;
                 const uint64_t ec = e[j];
-                const uint64_t nxt0 = __shfl(e[(j + 1) % D], 0);
-                uint64_t ep = __shfl_up(ec, 1);
-                uint64_t en = __shfl_down(ec, 1);
-                if (lane == 0) ep = prev_last;
-                if (lane == kWave - 1) en = nxt0;
-                prev_last = __shfl(ec, kWave - 1);
+                const uint64_t nxt0 = wave_read(e[(j + 1) % D], 0);
+                const uint64_t ep = wave_from_below(ec, prev_last);
+                const uint64_t en = wave_from_above(ec, nxt0);
+                prev_last = wave_read(ec, kWave - 1);
                 e[j] = 0;
                 if (k + D * kWave < m) e[j] = cur[k + D * kWave];
                 RunFlags f;
@@ -1833,7 +1831,7 @@ __device__ __noinline__ uint32_t resolve_periodic_groups(const uint64_t* __restr
             if (base >= hi) break;  // wave-uniform
             const bool valid = base + lane < hi;
             const uint32_t g = (uint32_t)(es[u] >> gshift), idx = (uint32_t)(es[u] & imask);
-            const uint32_t g0 = __shfl(g, 0);
+            const uint32_t g0 = wave_read(g, 0);
             if (__ballot(valid && g != g0) == 0ull) {
                 uint32_t mn = valid ? idx : 0xFFFFFFFFu, mx = valid ? idx : 0u;
 #pragma unroll
@@ -2052,8 +2050,8 @@ __device__ __forceinline__ ShortGroups short_groups(const ShortLoad& ld, uint32_
     const uint64_t before = ld.before;
     r.idx = (uint32_t)(r.e & imask);
     const uint64_t g = r.e >> gshift;
-    uint64_t gp = __shfl_up(g, 1);
-    if (lane == 0) gp = base ? before >> gshift : ~g;
+    const uint64_t g_first = wave_read(g, 0);
+    const uint64_t gp = wave_from_below(g, base ? before >> gshift : ~g_first);
     const uint64_t H = __ballot(valid && g != gp);  // first elements of groups
     const uint64_t upto = H & lanemask_le();
     r.head = upto ? 63u - (uint32_t)__clzll(upto) : 64u;  // 64: my group began before this vector
@@ -2466,7 +2464,7 @@ __device__ __noinline__ bool expand_periodic_block(const uint8_t* __restrict__ t
         const uint32_t wt = r < hi ? weight(sa2[r]) : 0u;
         const uint32_t incl = wave_inclusive_scan(wt);
         if (r < hi) rowstart[r] = run + incl - wt;
-        run += __shfl(incl, kWave - 1);
+        run += wave_read(incl, kWave - 1);
     }
     __syncthreads();
     if (total != len + 1u) return false;  // workgroup-uniform
