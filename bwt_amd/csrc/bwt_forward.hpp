@@ -1602,13 +1602,18 @@ __device__ __forceinline__ void rerank_chunk(uint32_t cnt, uint64_t* __restrict_
     {
         uint32_t v = 0;
         for (uint32_t base = lo; base < hi; base += U * kWave, v += U) {
+            // one read per element (clamped: the flags sort out validity); the neighbours come from the
+            // neighbouring lanes, the elements before the first and after the last vector from LDS
             uint64_t y[U], yp[U], yn[U];
 #pragma unroll
+            for (int u = 0; u < U; ++u) y[u] = ls[min(base + (uint32_t)(u * kWave + lane), kmax)];
+            const uint64_t before = ls[min(base - 1u, kmax)], after = ls[min(base + (uint32_t)(U * kWave), kmax)];
+#pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t k = base + (uint32_t)(u * kWave + lane);
-                y[u] = ls[min(k, kmax)];
-                yp[u] = ls[min(k - 1u, kmax)];
-                yn[u] = ls[min(k + 1u, kmax)];
+                const uint64_t first = u == 0 ? before : wave_read(y[u == 0 ? 0 : u - 1], kWave - 1);
+                const uint64_t last = u == U - 1 ? after : wave_read(y[u == U - 1 ? u : u + 1], 0);
+                yp[u] = wave_from_below(y[u], first);
+                yn[u] = wave_from_above(y[u], last);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
