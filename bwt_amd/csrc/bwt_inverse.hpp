@@ -84,6 +84,7 @@ constexpr int kSegThreads = BWT_SEG_THREADS;  // workgroup size of the place ker
                                              // staging slot per segment = 4 x that many bytes (InvArgs::slot)
 constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 constexpr uint32_t kModeMulti = 0, kModeSingle = 1, kModeNone = 2;
+constexpr uint32_t kModeDone = 3;  // the block's text has been written already (bwt_inverse_packed_kernel)
 
 struct InvArgs {
     const uint8_t* in;    // block b reads in + b*(block_size+1)
@@ -125,6 +126,7 @@ struct InvArgs {
     // the last one.  `delim` is 256 then (no byte matches it).
     const uint32_t* orig_ptr;
     uint32_t out_stride;  // block b's text starts at out + b * out_stride (block_size; origin-pointer blocks: block_size + 1)
+    uint32_t packed_first;  // bwt_inverse_packed_kernel has run over the batch: mode[] is valid, blocks in kModeDone are finished
 };
 
 template <int NT>
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(NT) void bwt_inverse_build_kernel(InvArgs a) {
         const uint32_t b = sh.blk;
         __syncthreads();
         if (b >= a.nblocks) break;
+        if (a.packed_first && a.mode[b] == kModeDone) continue;  // workgroup-uniform
         const uint32_t n = inv_block_len(a, b);
         const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
         uint32_t* __restrict__ T = (uint32_t*)a.T + (uint64_t)b * a.tstride;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
     const uint32_t b = blockIdx.x * kWave + threadIdx.x;
     if (b >= a.nblocks) return;
     const uint32_t mode = a.mode[b];
-    if (mode == kModeMulti) return;
+    if (mode == kModeMulti || mode == kModeDone) return;
     const uint32_t n = inv_block_len(a, b);
     const uint32_t len = n - 1;
     uint32_t row = a.drow[b];

@@ -1,0 +1,464 @@
+// bwt_inverse_packed.hpp -- inverse BWT of blocks over at most FOUR text symbols (DNA), inside LDS.
+//
+// The general inverse (bwt_inverse.hpp) spends one dependent 4-byte load from the L2 per output
+// byte on the LF table T[i] = C[L[i]] + occ[i] (reference src/inverse_bwt.cpp:23-45 builds the same
+// numbers as arrays).  A block whose text has at most four distinct byte values needs no table: the
+// last column packs into two bits per row, and
+//      LF(row) = C[s] + number of s among the rows above     (s = the row's symbol)
+// is a sampled count plus a population count.  Per 64 text rows the workgroup keeps, in LDS,
+//      { C[a] + #a above, C[b] + #b above, C[c] + #c above, C[d] + #d above }   (16 bytes)
+//      { low bits of the 64 codes, high bits of the 64 codes }                     (16 bytes)
+// -- 128 KB for a block of 256 KiB -- so a walk step is two LDS reads and a few dozen integer
+// instructions instead of a trip to the L2.  The delimiter's row is taken OUT of the packed rows (the
+// rows above it move down by one), so that counts over the packed rows are counts over text symbols.
+//
+// One workgroup of 1024 lanes per block, everything for that block in one go:
+//   sample   the first bytes name the (at most four) text symbols; any other byte value met later,
+//            more or fewer than one delimiter, or a block outside the size range leaves the block
+//            to the general kernels (its mode stays != kModeDone)
+//   pack     16 rows per lane and step: byte -> code through a 256-byte table, two bit planes
+//   counts   per-group symbol counts -> exclusive scan -> the samples; C[] as in the reference
+//            (unsigned byte order, the delimiter counted where its value falls)
+//   walk 1   the chain is cut where q * A mod 2^k < ids (q = the packed row; the image is the segment's id) and at
+//            the delimiter row; lanes take segment ids until none is left and record {length,
+//            segment run into}
+//   order    pointer jumping over the records: bytes from a segment's start to the text's start
+//   walk 2   the same walks again, now writing bytes (back to front, a dword every four steps) to
+//            where the order step says they go; the long segments are handed out first
+// The result is the chain the reference walks (src/inverse_bwt.cpp:48-62), byte for byte; a
+// hand-made block whose LF permutation has several cycles yields the cycle through the delimiter
+// row, like the reference, with the shorter length in lens[].
+#pragma once
+#include "bwt_inverse.hpp"
+
+namespace bwtgpu {
+
+constexpr int kPackThreads = 1024;
+constexpr uint32_t kPackMaxRows = 262144u + 1u;  // block_size + 1 at most: the bit planes of more rows do not fit
+constexpr uint32_t kPackMinRows = 8192u;         // shorter blocks: the general kernels run several per compute unit
+constexpr uint32_t kPackGroups = (kPackMaxRows + 63u) / 64u;  // groups of 64 rows while the delimiter row is still in
+constexpr uint32_t kPackIds = 7936u;             // segment ids (LDS holds one record each); id kPackIds = the chain's first segment
+constexpr uint32_t kPackEnd = 8191u;             // "runs into the delimiter row"
+constexpr uint32_t kPackNextBits = 13;
+
+struct PackShared {
+    uint4 planes[kPackGroups];    // per 64 rows: low bits of the codes (x, y), high bits (z, w)
+    uint4 samp[kPackGroups];      // per 64 rows: the row LF leads to from the group's first row, for each of the four symbols
+    uint32_t seg[kPackIds + 1];   // walk 1: bytes << 13 | id of the segment run into (kPackEnd: none)
+                                  // walk 2: bytes from the segment's start to the text's start << 13 | min(own bytes, 8191); 0 = not on the chain
+    uint8_t lut[256];             // byte value -> code 0..3, 4 = delimiter, 0x80 = not in this block's alphabet
+    uint32_t wsum[kPackThreads / kWave];
+    uint64_t ball[4];
+    uint32_t cb[4];               // code -> byte value
+    uint32_t blk, ctr, ndelim, drow, bad;
+};
+static_assert(sizeof(PackShared) <= 160u * 1024u, "one workgroup's LDS");
+struct __attribute__((packed, aligned(1))) PackBytes16 {
+    uint32_t x, y, z, w;
+};
+struct __attribute__((packed, aligned(1))) PackBytes4 {
+    uint32_t x;
+};
+
+__device__ __forceinline__ uint32_t pack_seg(uint32_t bytes, uint32_t next) { return (bytes << kPackNextBits) | next; }
+
+constexpr uint32_t kPackGrabBatch = 8;   // lanes of a wave that wait for a segment before the wave hands ids out
+constexpr uint32_t kPackIdChunk = 64;    // ids a wave takes from the workgroup's counter at a time
+constexpr uint32_t kPackLong = 48;       // walk 2 hands out the segments of at least this many bytes first
+
+// Both walks.  EMIT = false: lengths and links into sh.seg.  EMIT = true: the bytes go to
+// out_end[-(total - togo) - 1] downwards, togo from sh.seg.
+// A lane's state is the PACKED row q it stands on (text rows only: q = row - (row > drow)).  The loop
+// is flat on purpose -- every iteration is one step of every walking lane, nothing inside the step
+// branches -- and lanes whose segment has ended wait until kPackGrabBatch of the wave's lanes do, so
+// that the bookkeeping (the record or the last stores of the finished segment, the next id, its first
+// row) is paid once for several lanes; ids come from a range of kPackIdChunk that the wave owns.
+// Walk 2 knows every segment's length and goes through the ids twice, long segments first: the
+// workgroup is done when its last lane is, and a long segment started late would be that lane.
+// Returns the iterations the wave has made.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint32_t drow, uint32_t row0, uint32_t mul,
+                                                uint32_t inv, uint32_t mask, uint32_t ids, uint32_t cbytes,
+                                                uint8_t* out_end, uint32_t total) {
+    const uint8_t* const planes = reinterpret_cast<const uint8_t*>(sh.planes);
+    const uint8_t* const samp = reinterpret_cast<const uint8_t*>(sh.samp);
+    uint32_t id = 0, q = 0, len = 0, hit_next = 0;
+    uint32_t walking = 0, pending = 0;  // lane masks: 0 or all ones
+    // walk 2: bytes not yet stored (oldest in the highest bits), how many, one past the address of the oldest
+    uint32_t acc_lo = 0, acc_hi = 0, cnt = 0;
+    uint8_t* top = out_end;
+    uint32_t wnext = 0, wend = 0;  // the wave's ids (wave-uniform)
+    bool more = true;              // the workgroup's counter may have ids left (wave-uniform)
+    const uint32_t id_end = EMIT ? 2u * ids : ids;
+    if (threadIdx.x == 0) {  // the chain's first segment starts where the delimiter row leads
+        const uint32_t q0 = row0 - (row0 > drow ? 1u : 0u);
+        const uint32_t img = __umul24(q0, mul) & mask;
+        if (row0 == drow || img < ids) {  // ... which is a cut itself: an empty segment
+            if (!EMIT) sh.seg[kPackIds] = pack_seg(0u, row0 == drow ? kPackEnd : img);
+        } else {
+            walking = ~0u;
+            id = kPackIds;
+            q = q0;
+        }
+    }
+    auto store_dword = [&]() {  // the four oldest bytes
+        const uint32_t sh8 = (cnt - 4u) * 8u;
+        const uint64_t acc = ((uint64_t)acc_hi << 32) | acc_lo;
+        reinterpret_cast<PackBytes4*>(top - 4)->x = (uint32_t)(acc >> sh8);
+        top -= 4;
+        cnt -= 4u;
+    };
+    for (uint32_t it = 0;; ++it) {
+        const uint64_t idle = __ballot(walking == 0u);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (nidle == (uint32_t)kWave || (more && nidle >= kPackGrabBatch)) {  // wave-uniform
+            if (pending) {
+                if (EMIT) {
+                    if (cnt >= 4u) store_dword();
+                    for (uint32_t k = 0; k < cnt; ++k) top[-1 - (int)k] = (uint8_t)(acc_lo >> (8u * (cnt - 1u - k)));
+                    cnt = 0;
+                } else {
+                    sh.seg[id] = pack_seg(len, hit_next);
+                }
+                pending = 0;
+            }
+            if (!more) return it;  // nobody walks, nothing left
+            const uint32_t avail = wend - wnext;
+            const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
+            if (walking == 0u && rank < avail) {
+                uint32_t cand = wnext + rank;
+                const bool second = EMIT && cand >= ids;  // walk 2, second round: the short segments
+                if (second) cand -= ids;
+                const uint32_t q1 = __umul24(cand, inv) & mask;
+                bool ok = q1 < m;
+                if (EMIT && ok) {
+                    const uint32_t word = sh.seg[cand];
+                    const uint32_t togo = word >> kPackNextBits;
+                    ok = togo != 0u && togo <= total && ((word & kPackEnd) >= kPackLong) != second;
+                    top = out_end - (total - togo);
+                }
+                if (ok) {
+                    walking = ~0u;
+                    id = cand;
+                    q = q1;
+                    len = 0;
+                }
+            }
+            wnext += min(nidle, avail);
+            if (wnext == wend) {  // a new range for the wave
+                uint32_t v = 0;
+                if (lane_id() == 0) v = atomicAdd(&sh.ctr, kPackIdChunk);
+                wnext = wave_read(v, 0);
+                wend = min(wnext + kPackIdChunk, id_end);
+                if (wnext >= id_end) {
+                    more = false;
+                    wnext = wend = 0;
+                }
+            }
+        }
+        if (walking) {
+            const uint32_t off = (q >> 6) * 16u;
+            const uint4 pl = *reinterpret_cast<const uint4*>(planes + off);
+            const uint32_t up = 63u - (q & 63u);  // my row's bit goes to the top, the rows above me below it
+            const uint64_t lo = (((uint64_t)pl.y << 32) | pl.x) << up, hi = (((uint64_t)pl.w << 32) | pl.z) << up;
+            const uint32_t s0 = (uint32_t)((int32_t)(uint32_t)(lo >> 32) >> 31);  // all ones when the code's bit is set
+            const uint32_t s1 = (uint32_t)((int32_t)(uint32_t)(hi >> 32) >> 31);
+            const uint32_t next_row = *reinterpret_cast<const uint32_t*>(samp + off + ((s0 & 4u) | (s1 & 8u)));
+            // rows with my symbol: me, the rows above me, and -- for symbol 0 -- the `up` zeros shifted in
+            const uint32_t same_lo = ~(((uint32_t)lo ^ s0) | ((uint32_t)hi ^ s1));
+            const uint32_t same_hi = ~(((uint32_t)(lo >> 32) ^ s0) | ((uint32_t)(hi >> 32) ^ s1));
+            const uint32_t extra = 1u + (up & ~(s0 | s1));
+            const uint32_t row = next_row + (uint32_t)__popc(same_lo) + (uint32_t)__popc(same_hi) - extra;
+            ++len;
+            if (EMIT) {
+                const uint32_t byte = (cbytes >> ((s0 & 8u) | (s1 & 16u))) & 255u;
+                acc_hi = __builtin_amdgcn_alignbit(acc_hi, acc_lo, 24);
+                acc_lo = (acc_lo << 8) | byte;
+                ++cnt;
+            }
+            q = row - (row > drow ? 1u : 0u);
+            const uint32_t img = __umul24(q, mul) & mask;
+            const bool at_end = row == drow, cut = img < ids;
+            const bool hit = at_end | cut | (len > m);  // len > m: never (the chain through the delimiter row has at most m bytes)
+            hit_next = at_end | !cut ? kPackEnd : img;
+            walking = hit ? 0u : ~0u;
+            pending = hit ? ~0u : 0u;
+        }
+        if (EMIT && (it & 3u) == 3u && cnt >= 4u) store_dword();  // (it & 3) is wave-uniform: a lane holds at most 7 bytes
+    }
+}
+
+// -DBWT_PACK_CLOCKS: thread 0 of the workgroup that gets block 0 prints what each step took (s_memtime ticks)
+#ifdef BWT_PACK_CLOCKS
+#define PACK_CLK(p)                                            \
+    do {                                                       \
+        __syncthreads();                                       \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();    \
+        clk_[p] = (uint32_t)(now_ - last_);                    \
+        last_ = now_;                                          \
+    } while (0)
+#else
+#define PACK_CLK(p)
+#endif
+
+__global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArgs a) {
+    __shared__ PackShared sh;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+#ifdef BWT_PACK_CLOCKS
+    uint32_t clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t last_ = 0;
+#endif
+    for (;;) {
+        __syncthreads();  // everybody is done with the block before
+        if (tid == 0) {
+            sh.blk = atomicAdd(&a.queue[1], 1u);
+            sh.ndelim = 0;
+            sh.bad = 0;
+            sh.drow = kNoRow;
+        }
+        if (tid < 256) sh.lut[tid] = 0;
+        if (tid < 4) sh.cb[tid] = 0;
+        __syncthreads();
+        const uint32_t b = sh.blk;
+        if (b >= a.nblocks) break;
+        const uint32_t n = inv_block_len(a, b);
+        if (tid == 0) a.mode[b] = kModeNone;  // "not done here" until the end; the general build kernel sets the real mode
+        if (n < kPackMinRows || n > kPackMaxRows) continue;
+        const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
+#ifdef BWT_PACK_CLOCKS
+        last_ = __builtin_amdgcn_s_memtime();
+#endif
+
+        // ---- the alphabet, from the first 4096 bytes
+        for (uint32_t k = 0; k < 4u; ++k) sh.lut[L[4u * (uint32_t)tid + k]] = 1;  // n >= 8192
+        __syncthreads();
+        const bool present = tid < 256 && sh.lut[tid] != 0 && (uint32_t)tid != a.delim;
+        const uint64_t bal = __ballot(present);
+        if (w < 4 && lane == 0) sh.ball[w] = bal;
+        __syncthreads();
+        uint32_t sigma = 0, below = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = (uint32_t)__popcll(sh.ball[i]);
+            sigma += c;
+            if (i < w) below += c;
+        }
+        if (sigma > 4u || sigma == 0u) continue;  // workgroup-uniform
+        if (tid < 256) {
+            const uint32_t code = below + (uint32_t)__popcll(bal & lanemask_lt());
+            sh.lut[tid] = present ? (uint8_t)code : (uint32_t)tid == a.delim ? (uint8_t)4 : (uint8_t)0x80;
+            if (present) sh.cb[code] = (uint32_t)tid;
+        }
+        __syncthreads();
+        const uint32_t cbytes = sh.cb[0] | (sh.cb[1] << 8) | (sh.cb[2] << 16) | (sh.cb[3] << 24);
+
+        PACK_CLK(0);
+        // ---- pack: 16 rows per lane and step, the delimiter row still in (code 0)
+        const uint32_t groups = (n + 63u) / 64u;
+        for (uint32_t p = (uint32_t)tid; p < 4u * groups; p += kPackThreads) {
+            const uint32_t r0 = 16u * p;
+            uint32_t lo = 0, hi = 0, fl = 0;
+            if (r0 < n) {
+                uint32_t d[4];
+                if (r0 + 16u <= n) {
+                    const PackBytes16 v = *reinterpret_cast<const PackBytes16*>(L + r0);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                } else {  // the block's ragged end: padded with a text symbol
+                    d[0] = d[1] = d[2] = d[3] = (cbytes & 255u) * 0x01010101u;
+                    for (uint32_t k = 0; r0 + k < n; ++k)
+                        d[k >> 2] = (d[k >> 2] & ~(255u << (8u * (k & 3u)))) | ((uint32_t)L[r0 + k] << (8u * (k & 3u)));
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) {
+                    const uint32_t c = sh.lut[(d[k >> 2] >> (8u * (k & 3u))) & 255u];
+                    lo |= (c & 1u) << k;
+                    hi |= ((c >> 1) & 1u) << k;
+                    fl |= c;
+                }
+                if (fl & 0x84u) {  // rare: a delimiter, or a byte that is not in the alphabet
+                    if (fl & 0x80u) sh.bad = 1;
+                    if (fl & 4u)
+                        for (uint32_t k = 0; k < 16u; ++k)
+                            if (r0 + k < n && ((d[k >> 2] >> (8u * (k & 3u))) & 255u) == a.delim) {
+                                atomicAdd(&sh.ndelim, 1u);
+                                sh.drow = r0 + k;
+                            }
+                }
+            }
+            uint16_t* planes = reinterpret_cast<uint16_t*>(&sh.planes[p >> 2]);
+            planes[p & 3u] = (uint16_t)lo;
+            planes[4u + (p & 3u)] = (uint16_t)hi;
+        }
+        __syncthreads();
+        if (sh.bad || sh.ndelim != 1u) continue;  // workgroup-uniform: left to the general kernels
+        const uint32_t drow = sh.drow;
+        PACK_CLK(1);
+
+        // ---- take the delimiter row out: the rows above it move down by one
+        {
+            constexpr int K = (kPackGroups + kPackThreads - 1) / kPackThreads;
+            const uint32_t gd = drow >> 6, rd = drow & 63u;
+            uint64_t nlo[K], nhi[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t g = (uint32_t)tid + (uint32_t)k * kPackThreads;
+                nlo[k] = nhi[k] = 0;
+                if (g >= gd && g < groups) {
+                    const uint4 c = sh.planes[g];
+                    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                    if (g + 1u < groups) x = sh.planes[g + 1u];
+                    const uint64_t clo = ((uint64_t)c.y << 32) | c.x, chi = ((uint64_t)c.w << 32) | c.z;
+                    const uint64_t keep = g == gd ? (1ull << rd) - 1ull : 0ull;  // rows of the group below the delimiter row stay
+                    nlo[k] = (clo & keep) | ((clo >> 1) & ~keep) | ((uint64_t)(x.x & 1u) << 63);
+                    nhi[k] = (chi & keep) | ((chi >> 1) & ~keep) | ((uint64_t)(x.z & 1u) << 63);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t g = (uint32_t)tid + (uint32_t)k * kPackThreads;
+                if (g >= gd && g < groups)
+                    sh.planes[g] = make_uint4((uint32_t)nlo[k], (uint32_t)(nlo[k] >> 32), (uint32_t)nhi[k], (uint32_t)(nhi[k] >> 32));
+            }
+            __syncthreads();
+        }
+
+        PACK_CLK(2);
+        // ---- counts per group -> samples.  Thread t owns K consecutive groups of the m = n - 1 text rows.
+        const uint32_t m = n - 1u;
+        const uint32_t tgroups = (m + 63u) / 64u;
+        uint32_t row0;  // where the delimiter row leads: the delimiter's own place in the first column
+        {
+            constexpr int K = 4;  // tgroups <= 4096
+            const uint32_t per = (tgroups + kPackThreads - 1u) / kPackThreads;  // 1..4
+            uint32_t pre[K][4];
+            uint32_t run[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t g = (uint32_t)tid * per + (uint32_t)k;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pre[k][s] = run[s];
+                if ((uint32_t)k < per && g < tgroups) {
+                    const uint4 c = sh.planes[g];
+                    const uint32_t valid = min(64u, m - 64u * g);
+                    const uint64_t vm = valid == 64u ? ~0ull : (1ull << valid) - 1ull;
+                    const uint64_t clo = (((uint64_t)c.y << 32) | c.x), chi = (((uint64_t)c.w << 32) | c.z);
+                    const uint32_t c1 = (uint32_t)__popcll(clo & ~chi & vm), c2 = (uint32_t)__popcll(~clo & chi & vm),
+                                   c3 = (uint32_t)__popcll(clo & chi & vm);
+                    run[0] += valid - c1 - c2 - c3;
+                    run[1] += c1;
+                    run[2] += c2;
+                    run[3] += c3;
+                }
+            }
+            uint32_t base[4], tot[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) base[s] = block_exclusive_scan<kPackThreads>(run[s], sh.wsum, tot[s]);
+            // C[]: text symbols below, plus the delimiter when its value is below (reference src/inverse_bwt.cpp:35-45)
+            uint32_t C[4];
+            uint32_t acc = 0;
+            row0 = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool real = (uint32_t)s < sigma;
+                const bool dbelow = real && a.delim < ((cbytes >> (8 * s)) & 255u);
+                C[s] = acc + (dbelow ? 1u : 0u);
+                if (real && !dbelow) row0 += tot[s];
+                acc += tot[s];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t g = (uint32_t)tid * per + (uint32_t)k;
+                if ((uint32_t)k < per && g < tgroups)
+                    sh.samp[g] = make_uint4(C[0] + base[0] + pre[k][0], C[1] + base[1] + pre[k][1],
+                                                C[2] + base[2] + pre[k][2], C[3] + base[3] + pre[k][3]);
+            }
+        }
+        PACK_CLK(3);
+        // ---- cuts: packed row q -> q * mul mod 2^kbits (2^kbits >= m), a cut where the image is below `ids`
+        const uint32_t kbits = (uint32_t)bit_length(m - 1u);
+        const uint32_t mask = (1u << kbits) - 1u;
+        const uint32_t mul = ((uint32_t)(0.6180339887498949 * (double)(1u << kbits)) | 1u) & mask;
+        uint32_t inv = mul;  // Newton: inverse of an odd number modulo 2^32, five steps from 3 correct bits
+#pragma unroll
+        for (int i = 0; i < 5; ++i) inv *= 2u - mul * inv;
+        inv &= mask;
+        const uint32_t ids = min(kPackIds, (1u << kbits) >> 4);
+        for (uint32_t i = (uint32_t)tid; i <= kPackIds; i += kPackThreads) sh.seg[i] = pack_seg(0u, kPackEnd);
+        if (tid == 0) sh.ctr = 0;
+        __syncthreads();
+        uint8_t* const out_end = a.out + (uint64_t)b * a.out_stride + m;  // one past the text's last byte
+
+        const uint32_t its1 = packed_walk<false>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, 0u);
+        __syncthreads();
+        PACK_CLK(4);
+
+        // ---- order: every record becomes bytes from its segment's start to the text's start
+        uint32_t total;
+        {
+            constexpr int E = (kPackIds + 1 + kPackThreads - 1) / kPackThreads;
+            uint32_t own[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                own[e] = i <= kPackIds ? sh.seg[i] >> kPackNextBits : 0u;
+            }
+            for (int round = 0; round < (int)kPackNextBits; ++round) {
+                uint32_t nv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                    nv[e] = 0;
+                    if (i <= kPackIds) {
+                        const uint32_t word = sh.seg[i];
+                        const uint32_t next = word & kPackEnd;
+                        nv[e] = word;
+                        if (next != kPackEnd) {
+                            const uint32_t w2 = sh.seg[next];
+                            nv[e] = pack_seg((word >> kPackNextBits) + (w2 >> kPackNextBits), w2 & kPackEnd);
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                    if (i <= kPackIds) sh.seg[i] = nv[e];
+                }
+                __syncthreads();
+            }
+            const uint32_t first = sh.seg[kPackIds];
+            total = first >> kPackNextBits;
+            if ((first & kPackEnd) != kPackEnd || total > m) continue;  // never for a permutation; left to the general kernels
+            __syncthreads();
+            // for walk 2: where the segment's bytes go and how many they are; segments off the chain get 0
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                if (i <= kPackIds) {
+                    const uint32_t word = sh.seg[i];
+                    const bool on = (word & kPackEnd) == kPackEnd && own[e] != 0u && (word >> kPackNextBits) <= total;
+                    sh.seg[i] = on ? pack_seg(word >> kPackNextBits, min(own[e], kPackEnd)) : 0u;
+                }
+            }
+        }
+        PACK_CLK(5);
+        if (tid == 0) sh.ctr = 0;
+        __syncthreads();
+        const uint32_t its2 = packed_walk<true>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, total);
+        PACK_CLK(6);
+        (void)its1;
+        (void)its2;
+#ifdef BWT_PACK_CLOCKS
+        if (tid == 0 && b == 0)
+            printf("packed inverse, block 0 (%u rows): sample %u pack %u delete %u counts %u walk1 %u order %u walk2 %u ticks; wave 0: %u and %u iterations\n", n,
+                   clk_[0], clk_[1], clk_[2], clk_[3], clk_[4], clk_[5], clk_[6], its1, its2);
+#endif
+        if (tid == 0) {
+            a.lens[b] = total;
+            a.mode[b] = kModeDone;
+        }
+    }
+}
+
+}  // namespace bwtgpu

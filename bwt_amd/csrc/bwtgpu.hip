@@ -16,6 +16,7 @@
 #include "bwt_forward_small.hpp"
 #include "bwt_inverse.hpp"
 #include "bwt_inverse_small.hpp"
+#include "bwt_inverse_packed.hpp"
 #include "bwtgpu.h"
 
 namespace {
@@ -233,6 +234,7 @@ struct InvGeom {
     bool wide;   // blocks of more than kNarrowMaxRows rows: 64-bit table words
     uint32_t tile_rows, tiles_per_block;
     size_t dacc_off, thist_off;
+    uint32_t pack_wgs;  // workgroups of the in-LDS inverse of small-alphabet blocks (0: the batch's shape rules it out)
     size_t drow_off, mode_off, used_off, chain_off, seg_off, segrec_off, segovf_off, next_off, t_off, stage_off, pool_off, bytes;
 };
 
@@ -312,6 +314,7 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.stage_off = take(g.split ? g.nblocks * round_up(g.seg_cap, 64) * g.slot : 0);
     g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * g.slot : 0);
     g.t_off = take((size_t)g.tstride * (g.wide ? 8 : 4) * g.nblocks);
+    g.pack_wgs = !g.tiled && longest >= kPackMinRows && longest <= kPackMaxRows ? (uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus) : 0u;
     g.bytes = off;
     return g;
 }
@@ -891,6 +894,19 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
         hipLaunchKernelGGL(bwt_inverse_small_kernel, dim3(grid), dim3(kInvSmallWaves * kWave), 0, s, a);
         HIP_TRY(hipGetLastError());
         return BWTGPU_OK;
+    }
+    // Blocks over at most four text symbols are inverted inside LDS first (bwt_inverse_packed.hpp); the
+    // kernels below then skip the blocks that kernel has finished.  BWTGPU_INVERSE_PATH=general leaves
+    // it out (tests run both ways).
+    a.packed_first = 0;
+    {
+        const char* e = std::getenv("BWTGPU_INVERSE_PATH");
+        const bool general_only = e && !strcmp(e, "general");
+        if (!general_only && g.pack_wgs && !d_orig_ptr) {
+            a.packed_first = 1;
+            hipLaunchKernelGGL(bwt_inverse_packed_kernel, dim3(g.pack_wgs), dim3(kPackThreads), 0, s, a);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (g.tiled) {
         InvTileArgs ta;

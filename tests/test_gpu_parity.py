@@ -33,12 +33,21 @@ def forward_path(request):
     """Every test runs three times: with the library choosing between the batch kernels and the
     device-wide forward path by the shape of the input, and with either one forced."""
     old = os.environ.get("BWTGPU_FORWARD_PATH")
+    old_inv = os.environ.get("BWTGPU_INVERSE_PATH")
     os.environ["BWTGPU_FORWARD_PATH"] = request.param
+    # the "block" runs also keep the inverse on the general kernels (no in-LDS inverse of
+    # small-alphabet blocks), so both inverse routes see every case
+    if request.param == "block":
+        os.environ["BWTGPU_INVERSE_PATH"] = "general"
     yield request.param
     if old is None:
         del os.environ["BWTGPU_FORWARD_PATH"]
     else:
         os.environ["BWTGPU_FORWARD_PATH"] = old
+    if old_inv is None:
+        os.environ.pop("BWTGPU_INVERSE_PATH", None)
+    else:
+        os.environ["BWTGPU_INVERSE_PATH"] = old_inv
 
 
 def test_known_answers(known_answers):
@@ -106,6 +115,53 @@ def test_inverse_errors_and_misuse(orc):
     L = api.lib()
     assert not L.bwtgpu_pipeline_create(0, 0, api.MAX_BLOCK_SIZE + 1, 1, 1)
     assert "exceeds the supported maximum" in api.last_error()
+
+
+def test_small_alphabet_inverse(orc):
+    """Blocks over at most four text symbols (inverted inside LDS from two bits per row): every
+    alphabet size, the delimiter below / between / above the symbols, block lengths around the
+    size limits and around multiples of 64 rows, the delimiter row at either end of the block,
+    a symbol that first appears late (the block falls back to the general kernels), batches
+    that mix such blocks with ordinary ones, and hand-made blocks with several LF cycles."""
+    rng = np.random.default_rng(4242)
+    cases = []
+    for n in [8191, 8192, 8255, 8256, 8257, 20000, 65536, 131071, 262143, 262144]:
+        for symbols, delim in [(b"ACGT", 0), (b"ACGT", ord("D")), (b"ACGT", 255), (b"ab", ord("a") + 3), (b"x", 7),
+                               (bytes([0, 1, 2]), 3), (bytes([1, 254, 255]), 0)]:
+            if n > 70000 and symbols != b"ACGT":
+                continue
+            idx = rng.integers(0, len(symbols), size=n)
+            cases.append((np.frombuffer(symbols, np.uint8)[idx].tobytes(), delim))
+    for data, delim in cases:
+        fwd = orc.forward(data, delim)
+        assert api.bwt_inverse(fwd, delim) == data, (len(data), delim)
+    # delimiter row first / last: text that sorts entirely above or below the delimiter
+    for data, delim in [(b"C" * 9000, ord("A")), (b"C" * 9000, ord("T")), (b"AC" * 5000, ord("B"))]:
+        assert api.bwt_inverse(orc.forward(data, delim), delim) == data
+    # a fifth symbol beyond the sampled prefix
+    late = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=100000)].tobytes())
+    late[77777] = ord("N")
+    assert api.bwt_inverse(orc.forward(bytes(late), 0), 0) == bytes(late)
+    # mixed batch: ACGT, random bytes, two symbols, ragged ACGT tail
+    bs = 40000
+    parts = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=bs)], rng.integers(1, 200, size=bs, dtype=np.uint8),
+             np.frombuffer(b"AT", np.uint8)[rng.integers(0, 2, size=bs)], np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=12345)]]
+    data = np.concatenate(parts).astype(np.uint8).tobytes()
+    want = orc.forward_buffer(data, bs, 4)
+    assert api.inverse_batch(want[1:], bs, want[0]) == data
+    # several LF cycles, small alphabets
+    prng = random.Random(9)
+    for n, sigma in [(9000, 1), (30000, 2), (70000, 4), (262145, 4)]:
+        blk = bytearray(prng.randrange(1, 1 + sigma) for _ in range(n))
+        blk[prng.randrange(n)] = 0
+        assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0), (n, sigma)
+    # no delimiter / two delimiters in a small-alphabet block
+    blk = bytearray(b"ACGT" * 3000)
+    with pytest.raises(api.BwtGpuError):
+        api.bwt_inverse(bytes(blk), 0)
+    blk[5] = 0
+    blk[7000] = 0
+    assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0)
 
 
 def test_find_unused_byte():
