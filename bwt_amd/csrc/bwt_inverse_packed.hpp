@@ -13,7 +13,8 @@
 // rows above it move down by one), so that counts over the packed rows are counts over text symbols.
 //
 // One workgroup of 1024 lanes per block, everything for that block in one go:
-//   sample   the first bytes name the (at most four) text symbols; any other byte value met later,
+//   (bwt_inverse_packed_classify_kernel lists the blocks whose first 64 bytes allow it)
+//   sample   the first 4096 bytes name the (at most four) text symbols; any other byte value met later,
 //            more or fewer than one delimiter, or a block outside the size range leaves the block
 //            to the general kernels (its mode stays != kModeDone)
 //   pack     16 rows per lane and step: byte -> code through a 256-byte table, two bit planes
@@ -82,14 +83,20 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
                                                 uint8_t* out_end, uint32_t total) {
     const uint8_t* const planes = reinterpret_cast<const uint8_t*>(sh.planes);
     const uint8_t* const samp = reinterpret_cast<const uint8_t*>(sh.samp);
-    uint32_t id = 0, q = 0, len = 0, hit_next = 0;
-    uint32_t walking = 0, pending = 0;  // lane masks: 0 or all ones
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t id = kNone;  // the segment the lane walks, or has walked and not yet put on record
+    uint32_t q = 0, len = 0, hit_next = 0;
+    uint32_t walking = 0;  // lane mask: 0 or all ones
     // walk 2: bytes not yet stored (oldest in the highest bits), how many, one past the address of the oldest
     uint32_t acc_lo = 0, acc_hi = 0, cnt = 0;
     uint8_t* top = out_end;
     uint32_t wnext = 0, wend = 0;  // the wave's ids (wave-uniform)
     bool more = true;              // the workgroup's counter may have ids left (wave-uniform)
     const uint32_t id_end = EMIT ? 2u * ids : ids;
+    // No walk is longer than m steps and a lane that waits is served within a few iterations; the bound
+    // only keeps a workgroup from spinning should its tables ever be inconsistent (the block is then
+    // left to the general kernels).
+    const uint32_t it_cap = 4u * m + 65536u;
     if (threadIdx.x == 0) {  // the chain's first segment starts where the delimiter row leads
         const uint32_t q0 = row0 - (row0 > drow ? 1u : 0u);
         const uint32_t img = __umul24(q0, mul) & mask;
@@ -112,7 +119,7 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
         const uint64_t idle = __ballot(walking == 0u);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (nidle == (uint32_t)kWave || (more && nidle >= kPackGrabBatch)) {  // wave-uniform
-            if (pending) {
+            if (walking == 0u && id != kNone) {  // a finished segment
                 if (EMIT) {
                     if (cnt >= 4u) store_dword();
                     for (uint32_t k = 0; k < cnt; ++k) top[-1 - (int)k] = (uint8_t)(acc_lo >> (8u * (cnt - 1u - k)));
@@ -120,7 +127,7 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
                 } else {
                     sh.seg[id] = pack_seg(len, hit_next);
                 }
-                pending = 0;
+                id = kNone;
             }
             if (!more) return it;  // nobody walks, nothing left
             const uint32_t avail = wend - wnext;
@@ -156,6 +163,10 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
                 }
             }
         }
+        if (it > it_cap) {  // wave-uniform; never
+            sh.bad = 1;
+            return it;
+        }
         if (walking) {
             const uint32_t off = (q >> 6) * 16u;
             const uint4 pl = *reinterpret_cast<const uint4*>(planes + off);
@@ -163,6 +174,8 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
             const uint64_t lo = (((uint64_t)pl.y << 32) | pl.x) << up, hi = (((uint64_t)pl.w << 32) | pl.z) << up;
             const uint32_t s0 = (uint32_t)((int32_t)(uint32_t)(lo >> 32) >> 31);  // all ones when the code's bit is set
             const uint32_t s1 = (uint32_t)((int32_t)(uint32_t)(hi >> 32) >> 31);
+            // one word, read once the symbol is known: fetching all four beside the planes and choosing in
+            // registers was slower (the loop is bound by LDS traffic)
             const uint32_t next_row = *reinterpret_cast<const uint32_t*>(samp + off + ((s0 & 4u) | (s1 & 8u)));
             // rows with my symbol: me, the rows above me, and -- for symbol 0 -- the `up` zeros shifted in
             const uint32_t same_lo = ~(((uint32_t)lo ^ s0) | ((uint32_t)hi ^ s1));
@@ -179,10 +192,8 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
             q = row - (row > drow ? 1u : 0u);
             const uint32_t img = __umul24(q, mul) & mask;
             const bool at_end = row == drow, cut = img < ids;
-            const bool hit = at_end | cut | (len > m);  // len > m: never (the chain through the delimiter row has at most m bytes)
-            hit_next = at_end | !cut ? kPackEnd : img;
-            walking = hit ? 0u : ~0u;
-            pending = hit ? ~0u : 0u;
+            hit_next = at_end ? kPackEnd : img;
+            walking = at_end | cut ? 0u : ~0u;
         }
         if (EMIT && (it & 3u) == 3u && cnt >= 4u) store_dword();  // (it & 3) is wave-uniform: a lane holds at most 7 bytes
     }
@@ -201,6 +212,29 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
 #define PACK_CLK(p)
 #endif
 
+// Which blocks are worth a try: one wave per block looks at the block's first 64 bytes and lists the
+// block (queue[2] counts, the list is in a.drow, which the table kernels fill only later) when they
+// hold at most four byte values besides the delimiter.  Random bytes and text are ruled out here
+// for the price of one cache line; every block's mode is set to "not done".
+constexpr int kPackClassifyThreads = 256;
+__global__ __launch_bounds__(kPackClassifyThreads) void bwt_inverse_packed_classify_kernel(InvArgs a) {
+    const uint32_t b = blockIdx.x * (uint32_t)(kPackClassifyThreads / kWave) + (uint32_t)wave_id();
+    if (b >= a.nblocks) return;  // wave-uniform
+    const int lane = lane_id();
+    if (lane == 0) a.mode[b] = kModeNone;
+    const uint32_t n = inv_block_len(a, b);
+    if (n < kPackMinRows || n > kPackMaxRows) return;
+    const uint32_t byte = a.in[(uint64_t)b * ((uint64_t)a.block_size + 1u) + (uint32_t)lane];
+    uint64_t rest = __ballot(byte != a.delim);
+    uint32_t values = 0;
+    while (rest && values <= 4u) {
+        const uint32_t v = wave_read(byte, (int)__builtin_ctzll(rest));
+        rest &= ~__ballot(byte == v);
+        ++values;
+    }
+    if (rest == 0ull && values >= 1u && values <= 4u && lane == 0) a.drow[atomicAdd(&a.queue[2], 1u)] = b;
+}
+
 __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArgs a) {
     __shared__ PackShared sh;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -211,7 +245,8 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
     for (;;) {
         __syncthreads();  // everybody is done with the block before
         if (tid == 0) {
-            sh.blk = atomicAdd(&a.queue[1], 1u);
+            const uint32_t i = atomicAdd(&a.queue[1], 1u);  // the next listed block
+            sh.blk = i < a.queue[2] ? a.drow[i] : a.nblocks;
             sh.ndelim = 0;
             sh.bad = 0;
             sh.drow = kNoRow;
@@ -221,9 +256,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         __syncthreads();
         const uint32_t b = sh.blk;
         if (b >= a.nblocks) break;
-        const uint32_t n = inv_block_len(a, b);
-        if (tid == 0) a.mode[b] = kModeNone;  // "not done here" until the end; the general build kernel sets the real mode
-        if (n < kPackMinRows || n > kPackMaxRows) continue;
+        const uint32_t n = inv_block_len(a, b);  // kPackMinRows .. kPackMaxRows: listed
         const uint8_t* __restrict__ L = a.in + (uint64_t)b * ((uint64_t)a.block_size + 1u);
 #ifdef BWT_PACK_CLOCKS
         last_ = __builtin_amdgcn_s_memtime();
@@ -392,6 +425,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         const uint32_t its1 = packed_walk<false>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, 0u);
         __syncthreads();
         PACK_CLK(4);
+        if (sh.bad) continue;  // workgroup-uniform; never
 
         // ---- order: every record becomes bytes from its segment's start to the text's start
         uint32_t total;
@@ -446,6 +480,8 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         if (tid == 0) sh.ctr = 0;
         __syncthreads();
         const uint32_t its2 = packed_walk<true>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, total);
+        __syncthreads();
+        if (sh.bad) continue;  // workgroup-uniform; never
         PACK_CLK(6);
         (void)its1;
         (void)its2;

@@ -904,6 +904,9 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
         const bool general_only = e && !strcmp(e, "general");
         if (!general_only && g.pack_wgs && !d_orig_ptr) {
             a.packed_first = 1;
+            hipLaunchKernelGGL(bwt_inverse_packed_classify_kernel,
+                               dim3((uint32_t)((g.nblocks + kPackClassifyThreads / kWave - 1) / (kPackClassifyThreads / kWave))),
+                               dim3(kPackClassifyThreads), 0, s, a);
             hipLaunchKernelGGL(bwt_inverse_packed_kernel, dim3(g.pack_wgs), dim3(kPackThreads), 0, s, a);
             HIP_TRY(hipGetLastError());
         }
