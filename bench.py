@@ -246,7 +246,7 @@ def main() -> None:
         algo = 2 * nbytes + nblocks
         out = {}
         for key, ms, what in (("roofline", fwd_ms, "forward pass (all its launches: bwt_forward_kernel x2, or the device-wide path for few large blocks)"),
-                              ("roofline_inverse", inv_ms, "inverse pass (all its launches: table build, walk, stitch, place)")):
+                              ("roofline_inverse", inv_ms, "inverse pass (all its launches: in-LDS inverse of blocks over at most four symbols; table build, walk, stitch, place for the others)")):
             out[key] = {"bound": "hbm", "kernel": what, "achieved": algo / (ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / (ms * 1e-3) / HBM_PEAK,
                         "traffic": None, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms}

@@ -41,17 +41,21 @@ constexpr uint32_t kPackGroups = (kPackMaxRows + 63u) / 64u;  // groups of 64 ro
 constexpr uint32_t kPackIds = 7936u;             // segment ids (LDS holds one record each); id kPackIds = the chain's first segment
 constexpr uint32_t kPackEnd = 8191u;             // "runs into the delimiter row"
 constexpr uint32_t kPackNextBits = 13;
+constexpr uint32_t kPackStretches = 8;           // walk 2 writes the text in this many stretches, last stretch first
+constexpr uint32_t kPackBuckets = 2 * kPackStretches;  // ... and in each stretch the long segments before the short
 
 struct PackShared {
     uint4 planes[kPackGroups];    // per 64 rows: low bits of the codes (x, y), high bits (z, w)
     uint4 samp[kPackGroups];      // per 64 rows: the row LF leads to from the group's first row, for each of the four symbols
-    uint32_t seg[kPackIds + 1];   // walk 1: bytes << 13 | id of the segment run into (kPackEnd: none)
-                                  // walk 2: bytes from the segment's start to the text's start << 13 | min(own bytes, 8191); 0 = not on the chain
+    uint32_t seg[kPackIds + 1];   // walk 1, by segment id: bytes << 13 | id of the segment run into (kPackEnd: none)
+                                  // walk 2, the segments on the chain in the order they are handed out:
+                                  // bytes from the segment's start to the text's start << 13 | id
     uint8_t lut[256];             // byte value -> code 0..3, 4 = delimiter, 0x80 = not in this block's alphabet
     uint32_t wsum[kPackThreads / kWave];
     uint64_t ball[4];
     uint32_t cb[4];               // code -> byte value
     uint32_t blk, ctr, ndelim, drow, bad;
+    uint32_t bucket_fill[kPackBuckets], bucket_base[kPackBuckets + 1];  // the order of walk 2
 };
 static_assert(sizeof(PackShared) <= 160u * 1024u, "one workgroup's LDS");
 struct __attribute__((packed, aligned(1))) PackBytes16 {
@@ -74,13 +78,17 @@ constexpr uint32_t kPackLong = 48;       // walk 2 hands out the segments of at 
 // branches -- and lanes whose segment has ended wait until kPackGrabBatch of the wave's lanes do, so
 // that the bookkeeping (the record or the last stores of the finished segment, the next id, its first
 // row) is paid once for several lanes; ids come from a range of kPackIdChunk that the wave owns.
-// Walk 2 knows every segment's length and goes through the ids twice, long segments first: the
-// workgroup is done when its last lane is, and a long segment started late would be that lane.
+// Walk 2 takes the segments in the order the order step has laid out in sh.seg (`count` of them): the
+// text stretch by stretch, so that what the workgroup's lanes write at any time lies within a few
+// tens of KB and the dword stores of neighbouring segments meet in the L2 (handed out by id, they were
+// scattered over the whole block and every line left the L2 in pieces: nine times the text in HBM
+// writes); within a stretch the long segments first -- the workgroup is done when its last lane is,
+// and a long segment started late would be that lane.
 // Returns the iterations the wave has made.
 template <bool EMIT>
 __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint32_t drow, uint32_t row0, uint32_t mul,
                                                 uint32_t inv, uint32_t mask, uint32_t ids, uint32_t cbytes,
-                                                uint8_t* out_end, uint32_t total) {
+                                                uint8_t* out_end, uint32_t total, uint32_t count) {
     const uint8_t* const planes = reinterpret_cast<const uint8_t*>(sh.planes);
     const uint8_t* const samp = reinterpret_cast<const uint8_t*>(sh.samp);
     constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -92,7 +100,7 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
     uint8_t* top = out_end;
     uint32_t wnext = 0, wend = 0;  // the wave's ids (wave-uniform)
     bool more = true;              // the workgroup's counter may have ids left (wave-uniform)
-    const uint32_t id_end = EMIT ? 2u * ids : ids;
+    const uint32_t id_end = EMIT ? count : ids;
     // No walk is longer than m steps and a lane that waits is served within a few iterations; the bound
     // only keeps a workgroup from spinning should its tables ever be inconsistent (the block is then
     // left to the general kernels).
@@ -134,16 +142,16 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
             const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
             if (walking == 0u && rank < avail) {
                 uint32_t cand = wnext + rank;
-                const bool second = EMIT && cand >= ids;  // walk 2, second round: the short segments
-                if (second) cand -= ids;
-                const uint32_t q1 = __umul24(cand, inv) & mask;
-                bool ok = q1 < m;
-                if (EMIT && ok) {
+                bool ok = true;
+                if (EMIT) {  // the cand-th segment of the order step's list
                     const uint32_t word = sh.seg[cand];
                     const uint32_t togo = word >> kPackNextBits;
-                    ok = togo != 0u && togo <= total && ((word & kPackEnd) >= kPackLong) != second;
+                    ok = togo != 0u && togo <= total;
                     top = out_end - (total - togo);
+                    cand = word & kPackEnd;
                 }
+                const uint32_t q1 = __umul24(cand, inv) & mask;
+                ok = ok && q1 < m;
                 if (ok) {
                     walking = ~0u;
                     id = cand;
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         }
         if (tid < 256) sh.lut[tid] = 0;
         if (tid < 4) sh.cb[tid] = 0;
+        if (tid < (int)kPackBuckets) sh.bucket_fill[tid] = 0;
         __syncthreads();
         const uint32_t b = sh.blk;
         if (b >= a.nblocks) break;
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         __syncthreads();
         uint8_t* const out_end = a.out + (uint64_t)b * a.out_stride + m;  // one past the text's last byte
 
-        const uint32_t its1 = packed_walk<false>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, 0u);
+        const uint32_t its1 = packed_walk<false>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, 0u, 0u);
         __syncthreads();
         PACK_CLK(4);
         if (sh.bad) continue;  // workgroup-uniform; never
@@ -465,21 +474,43 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
             total = first >> kPackNextBits;
             if ((first & kPackEnd) != kPackEnd || total > m) continue;  // never for a permutation; left to the general kernels
             __syncthreads();
-            // for walk 2: where the segment's bytes go and how many they are; segments off the chain get 0
+            // for walk 2: the segments on the chain (the first one is thread 0's), grouped by the stretch of
+            // the text they write -- the stretch at the text's end first -- and by long / short
+            const uint32_t stretch_shift = (uint32_t)max(bit_length(total ? total - 1u : 0u), 3) - 3u;
+            uint32_t word[E], bucket[E], slot[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
-                if (i <= kPackIds) {
-                    const uint32_t word = sh.seg[i];
-                    const bool on = (word & kPackEnd) == kPackEnd && own[e] != 0u && (word >> kPackNextBits) <= total;
-                    sh.seg[i] = on ? pack_seg(word >> kPackNextBits, min(own[e], kPackEnd)) : 0u;
+                word[e] = i < kPackIds ? sh.seg[i] : 0u;
+                const uint32_t togo = word[e] >> kPackNextBits;
+                const bool on = (word[e] & kPackEnd) == kPackEnd && own[e] != 0u && togo <= total && i < kPackIds;
+                bucket[e] = kPackBuckets;
+                slot[e] = 0;
+                if (on) {
+                    bucket[e] = min((total - togo) >> stretch_shift, kPackStretches - 1u) * 2u + (own[e] < kPackLong ? 1u : 0u);
+                    slot[e] = atomicAdd(&sh.bucket_fill[bucket[e]], 1u);
                 }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t run = 0;
+                for (uint32_t k = 0; k < kPackBuckets; ++k) {
+                    sh.bucket_base[k] = run;
+                    run += sh.bucket_fill[k];
+                }
+                sh.bucket_base[kPackBuckets] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                if (bucket[e] < kPackBuckets) sh.seg[sh.bucket_base[bucket[e]] + slot[e]] = pack_seg(word[e] >> kPackNextBits, i);
             }
         }
         PACK_CLK(5);
         if (tid == 0) sh.ctr = 0;
         __syncthreads();
-        const uint32_t its2 = packed_walk<true>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, total);
+        const uint32_t its2 = packed_walk<true>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, total, sh.bucket_base[kPackBuckets]);
         __syncthreads();
         if (sh.bad) continue;  // workgroup-uniform; never
         PACK_CLK(6);

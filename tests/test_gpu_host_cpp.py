@@ -189,6 +189,35 @@ def test_cli_round_trip_around_geometry_thresholds(tmp_path, bs, nblocks):
     assert np.array_equal(np.fromfile(b, dtype=np.uint8), data)
 
 
+# DNA files through the command-line tools: the inverse takes blocks over at most four symbols
+# inside LDS when a block has 8192 .. 262145 rows (on either side the table kernels run), also for
+# a slab pipeline whose last slab is short and for a file that mixes DNA with other bytes.
+@pytest.mark.parametrize("bs", [8190, 8191, 65536, 262144, 262145])
+def test_cli_dna_files(tmp_path, bs):
+    import numpy as np
+
+    from bwt_amd import synth
+
+    nblocks = 150 if bs < 100000 else 18
+    total = (nblocks - 1) * bs + bs // 2 + 3
+    data = synth.generate("acgt", 1000 + bs, 0, total)
+    if bs == 65536:  # a stretch of ordinary bytes in the middle: those blocks go to the table kernels
+        data[5 * bs + 100:8 * bs - 100] = synth.generate("random255", 3, 0, 3 * bs - 200)
+        data[data == 0] = 1
+    src, f, b = str(tmp_path / "in"), str(tmp_path / "f.bwt"), str(tmp_path / "out")
+    data.tofile(src)
+    r = run([os.path.join(BUILD, "bwt"), src, f, str(bs)])
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(f, dtype=np.uint8)
+    assert out.size == total + 1 + nblocks and out[0] == 0
+    _sample_blocks_equal_oracle(data, out, bs, 0, [0, 6, nblocks - 1])
+    for env in ({}, {"BWTGPU_INVERSE_PATH": "general"}):
+        r = subprocess.run([os.path.join(BUILD, "inverse_bwt"), f, b, str(bs)], cwd=ROOT, env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(np.fromfile(b, dtype=np.uint8), data), env
+
+
 @pytest.mark.parametrize("bs,slab", [(1279, 2048), (1280, 2048), (2048, 2048), (4095, 2048), (16383, 256),
                                      (19999, 256), (20000, 256)])
 def test_pipeline_sized_for_a_full_slab_takes_any_shorter_batch(bs, slab):

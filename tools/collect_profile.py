@@ -29,6 +29,10 @@ def algorithmic_bytes(kernel: str, n: int, nb: int):
     rows = n + nb
     if "bwt_forward_kernel" in kernel or "bwt_forward_small" in kernel:
         return n + rows  # text in, transformed blocks out
+    if "inverse_packed_kernel" in kernel:
+        return rows + n  # transformed bytes in, text out: everything between stays in LDS
+    if "inverse_packed_classify" in kernel:
+        return None  # one cache line per block
     if "inverse_build" in kernel or "inverse_tile_build" in kernel:
         return rows + 4 * rows  # transformed bytes in, one 32-bit LF word per row out
     if "inverse_tile_hist" in kernel:
