@@ -13,8 +13,8 @@
 // rows above it move down by one), so that counts over the packed rows are counts over text symbols.
 //
 // One workgroup of 1024 lanes per block, everything for that block in one go:
-//   (bwt_inverse_packed_classify_kernel lists the blocks whose first 64 bytes allow it)
-//   sample   the first 4096 bytes name the (at most four) text symbols; any other byte value met later,
+//   (bwt_inverse_packed_classify_kernel lists the blocks of which a sample of 64 bytes allows it)
+//   sample   256 bytes spread over the block name the (at most four) text symbols; any other byte value met later,
 //            more or fewer than one delimiter, or a block outside the size range leaves the block
 //            to the general kernels (its mode stays != kModeDone)
 //   pack     16 rows per lane and step: byte -> code through a 256-byte table, two bit planes
@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
 #define PACK_CLK(p)
 #endif
 
-// Which blocks are worth a try: one wave per block looks at the block's first 64 bytes and lists the
+// Which blocks are worth a try: one wave per block looks at 64 of the block's bytes and lists the
 // block (queue[2] counts, the list is in a.drow, which the table kernels fill only later) when they
 // hold at most four byte values besides the delimiter.  Random bytes and text are ruled out here
 // for the price of one cache line; every block's mode is set to "not done".
@@ -232,7 +232,9 @@ __global__ __launch_bounds__(kPackClassifyThreads) void bwt_inverse_packed_class
     if (lane == 0) a.mode[b] = kModeNone;
     const uint32_t n = inv_block_len(a, b);
     if (n < kPackMinRows || n > kPackMaxRows) return;
-    const uint32_t byte = a.in[(uint64_t)b * ((uint64_t)a.block_size + 1u) + (uint32_t)lane];
+    // 64 bytes spread over the block: a transform keeps equal symbols together (its first rows may well
+    // hold a single value whatever the text was), so a prefix would say little
+    const uint32_t byte = a.in[(uint64_t)b * ((uint64_t)a.block_size + 1u) + (uint32_t)lane * (n / (uint32_t)kWave)];
     uint64_t rest = __ballot(byte != a.delim);
     uint32_t values = 0;
     while (rest && values <= 4u) {
@@ -271,8 +273,9 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         last_ = __builtin_amdgcn_s_memtime();
 #endif
 
-        // ---- the alphabet, from the first 4096 bytes
-        for (uint32_t k = 0; k < 4u; ++k) sh.lut[L[4u * (uint32_t)tid + k]] = 1;  // n >= 8192
+        // ---- the alphabet, from 256 bytes spread over the block (a symbol they miss shows up in the pack
+        // step, which then leaves the block to the general kernels)
+        if (tid < 256) sh.lut[L[(uint32_t)tid * (n / 256u)]] = 1;
         __syncthreads();
         const bool present = tid < 256 && sh.lut[tid] != 0 && (uint32_t)tid != a.delim;
         const uint64_t bal = __ballot(present);
