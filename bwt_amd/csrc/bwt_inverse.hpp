@@ -587,7 +587,8 @@ __device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, u
     const uint32_t w = blockIdx.x, x = w & 7u, q = w >> 3;
     b = (q / wgs) * 8u + x;
     j = (q % wgs) * (uint32_t)NT + threadIdx.x;
-    return b < a.nblocks && a.mode[b] == kModeMulti;
+    // the mode is wave-uniform and not written by this kernel: a load the scalar unit can do
+    return b < a.nblocks && __ldg(&a.mode[b]) == kModeMulti;
 }
 // The walk runs in workgroups of a single wave: a workgroup's slot on its compute unit is taken until
 // its LONGEST segment is done (segment lengths are geometric, mean 16: the longest of 64 is about 76
@@ -1024,6 +1025,9 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     const uint32_t k0 = ((blockIdx.x >> 3) % wgs) * (uint32_t)kSegThreads;  // the workgroup's first segment on the chain
     const uint32_t k = k0 + threadIdx.x;
     if (b >= a.nblocks || k0 >= a.seg_cap) return;  // workgroup-uniform
+    // a block the in-LDS inverse has finished: out before anything else is fetched (a whole batch of such
+    // blocks still dispatches this grid)
+    if (a.packed_first && __ldg(&a.mode[b]) == kModeDone) return;
     const uint64_t sb = (uint64_t)b * a.seg_cap;
     const uint32_t mode = a.mode[b];
     const uint2 whole = a.chain[b];

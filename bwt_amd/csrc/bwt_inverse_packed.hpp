@@ -224,25 +224,45 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
 // block (queue[2] counts, the list is in a.drow, which the table kernels fill only later) when they
 // hold at most four byte values besides the delimiter.  Random bytes and text are ruled out here
 // for the price of one cache line; every block's mode is set to "not done".
-constexpr int kPackClassifyThreads = 256;
+constexpr int kPackClassifyThreads = 1024;
 __global__ __launch_bounds__(kPackClassifyThreads) void bwt_inverse_packed_classify_kernel(InvArgs a) {
-    const uint32_t b = blockIdx.x * (uint32_t)(kPackClassifyThreads / kWave) + (uint32_t)wave_id();
-    if (b >= a.nblocks) return;  // wave-uniform
-    const int lane = lane_id();
-    if (lane == 0) a.mode[b] = kModeNone;
-    const uint32_t n = inv_block_len(a, b);
-    if (n < kPackMinRows || n > kPackMaxRows) return;
-    // 64 bytes spread over the block: a transform keeps equal symbols together (its first rows may well
-    // hold a single value whatever the text was), so a prefix would say little
-    const uint32_t byte = a.in[(uint64_t)b * ((uint64_t)a.block_size + 1u) + (uint32_t)lane * (n / (uint32_t)kWave)];
-    uint64_t rest = __ballot(byte != a.delim);
-    uint32_t values = 0;
-    while (rest && values <= 4u) {
-        const uint32_t v = wave_read(byte, (int)__builtin_ctzll(rest));
-        rest &= ~__ballot(byte == v);
-        ++values;
+    constexpr int W = kPackClassifyThreads / kWave;
+    __shared__ uint32_t s_listed[W];  // block index, or kNoRow
+    __shared__ uint32_t s_base;
+    const int lane = lane_id(), w = wave_id();
+    const uint32_t b = blockIdx.x * (uint32_t)W + (uint32_t)w;
+    bool listed = false;
+    if (b < a.nblocks) {  // wave-uniform
+        if (lane == 0) a.mode[b] = kModeNone;
+        const uint32_t n = inv_block_len(a, b);
+        if (n >= kPackMinRows && n <= kPackMaxRows) {
+            // 64 bytes spread over the block: a transform keeps equal symbols together (its first rows may well
+            // hold a single value whatever the text was), so a prefix would say little
+            const uint32_t byte = a.in[(uint64_t)b * ((uint64_t)a.block_size + 1u) + (uint32_t)lane * (n / (uint32_t)kWave)];
+            uint64_t rest = __ballot(byte != a.delim);
+            uint32_t values = 0;
+            while (rest && values <= 4u) {
+                const uint32_t v = wave_read(byte, (int)__builtin_ctzll(rest));
+                rest &= ~__ballot(byte == v);
+                ++values;
+            }
+            listed = rest == 0ull && values >= 1u && values <= 4u;
+        }
     }
-    if (rest == 0ull && values >= 1u && values <= 4u && lane == 0) a.drow[atomicAdd(&a.queue[2], 1u)] = b;
+    if (lane == 0) s_listed[w] = listed ? b : kNoRow;
+    __syncthreads();
+    // one counter update per workgroup (one per block was 16 K updates of a single word: 0.19 ms)
+    if (threadIdx.x == 0) {
+        uint32_t count = 0;
+        for (int i = 0; i < W; ++i) count += s_listed[i] != kNoRow ? 1u : 0u;
+        s_base = count ? atomicAdd(&a.queue[2], count) : 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && listed) {
+        uint32_t at = s_base;
+        for (int i = 0; i < w; ++i) at += s_listed[i] != kNoRow ? 1u : 0u;
+        a.drow[at] = b;
+    }
 }
 
 __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArgs a) {

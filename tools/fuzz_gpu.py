@@ -4,7 +4,8 @@ usage: python tools/fuzz_gpu.py [trials] [seed] [big]
 Covers: alphabet sizes incl. powers of two (delimiter above / below / inside the alphabet),
 runs, periodic text, repeated blocks, lengths around the internal size thresholds, batches;
 every trial through one of the forward paths (the batch kernels, the device-wide path, or the
-library's own choice).
+library's own choice) and one of the inverse routes (blocks over at most four symbols inside LDS,
+or the table kernels for everything).
 """
 import os
 import random
@@ -62,6 +63,7 @@ for t in range(trials):
     mode = rng.random()
     path = prng.choice(["auto", "auto", "block", "grid"])
     os.environ["BWTGPU_FORWARD_PATH"] = path
+    os.environ["BWTGPU_INVERSE_PATH"] = prng.choice(["auto", "auto", "general"])  # in-LDS inverse of small alphabets, or the table kernels only
     if 0.05 <= big < 0.10:
         bs = n // rng.randrange(270, 280)
         try:
