@@ -126,6 +126,7 @@ struct InvArgs {
     // the last one.  `delim` is 256 then (no byte matches it).
     const uint32_t* orig_ptr;
     uint32_t out_stride;  // block b's text starts at out + b * out_stride (block_size; origin-pointer blocks: block_size + 1)
+    uint32_t* left_hint;    // host memory the device can write: blocks of this batch that the in-LDS inverse did NOT finish
     uint32_t packed_first;  // bwt_inverse_packed_kernel has run over the batch: mode[] is valid, blocks in kModeDone are finished
 };
 
@@ -582,9 +583,9 @@ __global__ __launch_bounds__(kWave) void bwt_inverse_walk_kernel(InvArgs a) {
 // Segment j < regular_splitters(n) starts at the row whose image is j, j == regular_splitters(n)
 // starts at the delimiter row.  (A regular splitter that IS the delimiter row is left to the latter.)
 template <int NT = kSegThreads>
-__device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t& b, uint32_t& j) {
+__device__ __forceinline__ bool segment_of_lane(const InvArgs& a, uint32_t w, uint32_t& b, uint32_t& j) {
     const uint32_t wgs = (a.seg_cap + (uint32_t)NT - 1u) / (uint32_t)NT;  // workgroups that cover one block's segments
-    const uint32_t w = blockIdx.x, x = w & 7u, q = w >> 3;
+    const uint32_t x = w & 7u, q = w >> 3;
     b = (q / wgs) * 8u + x;
     j = (q % wgs) * (uint32_t)NT + threadIdx.x;
     // the mode is wave-uniform and not written by this kernel: a load the scalar unit can do
@@ -597,10 +598,11 @@ constexpr int kWalkThreads = kWave;
 
 // Walks every segment once: its length, the splitter it runs into, and its bytes -- in walk
 // order, 16 at a time -- into the segment's staging slot (then chained pool chunks).
+// Workgroup w of the grid the text above describes; the kernel below runs one or several of them.
 template <typename TW>
-__global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel(InvArgs a) {
+__device__ __forceinline__ void walk_segments_unit(const InvArgs& a, uint32_t w) {
     uint32_t b, j;
-    if (!segment_of_lane<kWalkThreads>(a, b, j)) return;
+    if (!segment_of_lane<kWalkThreads>(a, w, b, j)) return;
     const uint32_t n = inv_block_len(a, b);
     const uint32_t nreg = regular_splitters(n, a.split_shift);
     if (j > nreg) return;
@@ -664,6 +666,21 @@ __global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel
         __builtin_nontemporal_store(val, reinterpret_cast<v4*>(buf + (((t & ~15u) & (a.slot - 1u)) >> 4) * gstride));
     }
     a.seg[sb + j] = make_uint2(t, stop == drow ? nreg : mul_mod(stop, a.split_mul[last], n));
+}
+// `units` workgroups' worth of work, normally one workgroup per unit.  When the in-LDS inverse of
+// small-alphabet blocks is expected to finish every block (it did so in the device's previous batch), the
+// host launches a grid capped at kSparseGrid workgroups that strides over the units instead of
+// dispatching millions of workgroups that return at once (the stride is a multiple of 8: a unit stays
+// on the XCD its index names).  Blocks that do need this kernel are still done then, only more slowly:
+// the stride gives up the order in which neighbouring workgroups share an XCD's L2.
+constexpr uint32_t kSparseGrid = 16384;
+template <typename TW, bool STRIDED>
+__global__ __launch_bounds__(kWalkThreads) void bwt_inverse_walk_segments_kernel(InvArgs a, uint32_t units) {
+    if (STRIDED) {
+        for (uint32_t w = blockIdx.x; w < units; w += gridDim.x) walk_segments_unit<TW>(a, w);
+    } else {
+        walk_segments_unit<TW>(a, blockIdx.x);
+    }
 }
 
 // Orders the segments of every split block: start at the delimiter row's segment, follow the
@@ -1010,9 +1027,9 @@ __device__ __forceinline__ void place_segment_direct(const InvArgs& a, uint32_t 
 
 constexpr uint32_t kPlaceWindow = 64u * kSegThreads;  // bytes of a workgroup's stretch that are assembled in LDS
 
-__global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a) {
-    __shared__ uint32_t s_buf[kPlaceWindow / 4 + 8];  // walk order; 16 bytes of slack for the alignment shift
-    __shared__ uint32_t s_wend[kSegThreads / kWave];
+// Workgroup w of the place pass (s_buf: kPlaceWindow / 4 + 8 words, walk order with 16 bytes of slack for
+// the alignment shift; s_wend: one word per wave).
+__device__ __forceinline__ void place_unit(const InvArgs& a, uint32_t w, uint32_t* s_buf, uint32_t* s_wend) {
 #ifdef BWT_STITCH_CLOCKS
     uint64_t clk_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1021,8 +1038,8 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
     // block's mode, its chain, the lane's records and lane 0's position fetched one after the other
     // and two barriers to pass the latter round there were five of them before the first staged byte.
     const uint32_t wgs = (a.seg_cap + (uint32_t)kSegThreads - 1u) / (uint32_t)kSegThreads;
-    const uint32_t b = ((blockIdx.x >> 3) / wgs) * 8u + (blockIdx.x & 7u);  // as in segment_of_lane
-    const uint32_t k0 = ((blockIdx.x >> 3) % wgs) * (uint32_t)kSegThreads;  // the workgroup's first segment on the chain
+    const uint32_t b = ((w >> 3) / wgs) * 8u + (w & 7u);  // as in segment_of_lane
+    const uint32_t k0 = ((w >> 3) % wgs) * (uint32_t)kSegThreads;  // the workgroup's first segment on the chain
     const uint32_t k = k0 + threadIdx.x;
     if (b >= a.nblocks || k0 >= a.seg_cap) return;  // workgroup-uniform
     // a block the in-LDS inverse has finished: out before anything else is fetched (a whole batch of such
@@ -1149,6 +1166,27 @@ __global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs 
         }
     }
     STITCH_CLK(8);
+}
+// `units` workgroups' worth of work: one workgroup per unit, or a capped grid striding over them (see
+// bwt_inverse_walk_segments_kernel).
+template <bool STRIDED>
+__global__ __launch_bounds__(kSegThreads) void bwt_inverse_place_kernel(InvArgs a, uint32_t units) {
+    __shared__ uint32_t s_buf[kPlaceWindow / 4 + 8];
+    __shared__ uint32_t s_wend[kSegThreads / kWave];
+    if (STRIDED) {
+        for (uint32_t w = blockIdx.x; w < units; w += gridDim.x) {
+            place_unit(a, w, s_buf, s_wend);
+            __syncthreads();  // the next unit reuses the buffers
+        }
+    } else {
+        place_unit(a, blockIdx.x, s_buf, s_wend);
+    }
+}
+
+// What the in-LDS inverse left to the kernels above, for the host to look at before its next batch
+// (queue[3] counts the blocks that kernel has finished).
+__global__ void bwt_inverse_left_kernel(InvArgs a) {
+    __hip_atomic_store(a.left_hint, a.nblocks - a.queue[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- origin-pointer blocks: the last step --------------------------------------------------------

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         if (tid == 0) {
             a.lens[b] = total;
             a.mode[b] = kModeDone;
+            atomicAdd(&a.queue[3], 1u);
         }
     }
 }

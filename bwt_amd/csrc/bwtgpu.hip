@@ -70,6 +70,12 @@ struct Device {
     hipStream_t stream = nullptr;
     uint8_t* static_ws = nullptr;  // this device's copy of `scratch` (nullptr: the lookup failed, see static_ws_error)
     hipError_t static_ws_error = hipSuccess;
+    // Pinned host word the device writes at the end of an inverse batch that went through the in-LDS inverse
+    // first: the blocks that kernel did not finish.  0 = the table kernels found nothing to do, and the
+    // next such batch launches them as small striding grids (a guess about the data: either way of
+    // launching gives the same bytes).
+    uint32_t* inv_left = nullptr;
+    uint32_t* inv_left_dev = nullptr;  // the same word as the device addresses it
     bool ready = false;
     std::mutex mu;          // one host-pointer call at a time per device
     std::mutex init_mu;     // guards first-use binding
@@ -442,6 +448,14 @@ int ensure_device(int device) {
     void* sp = nullptr;
     d->static_ws_error = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
     d->static_ws = d->static_ws_error == hipSuccess ? (uint8_t*)sp : nullptr;
+    if (hipHostMalloc((void**)&d->inv_left, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer((void**)&d->inv_left_dev, d->inv_left, 0) == hipSuccess) {
+        *d->inv_left = 0xFFFFFFFFu;
+    } else {
+        if (d->inv_left) (void)hipHostFree(d->inv_left);
+        d->inv_left = d->inv_left_dev = nullptr;
+        (void)hipGetLastError();
+    }
     d->ready = true;
     return BWTGPU_OK;
 }
@@ -727,6 +741,7 @@ void bwtgpu_shutdown(void) {
         if (d->d_ws) (void)hipFree(d->d_ws);
         if (d->d_aux) (void)hipFree(d->d_aux);
         if (d->stream) (void)hipStreamDestroy(d->stream);
+        if (d->inv_left) (void)hipHostFree(d->inv_left);
         delete d;
     }
     g_dev.clear();
@@ -899,11 +914,15 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
     // kernels below then skip the blocks that kernel has finished.  BWTGPU_INVERSE_PATH=general leaves
     // it out (tests run both ways).
     a.packed_first = 0;
+    a.left_hint = nullptr;
+    bool sparse = false;  // the device's previous batch left nothing to the table kernels: launch them as small grids
     {
         const char* e = std::getenv("BWTGPU_INVERSE_PATH");
         const bool general_only = e && !strcmp(e, "general");
         if (!general_only && g.pack_wgs && !d_orig_ptr) {
             a.packed_first = 1;
+            a.left_hint = d.inv_left_dev;
+            sparse = d.inv_left && __atomic_load_n(d.inv_left, __ATOMIC_RELAXED) == 0u;
             hipLaunchKernelGGL(bwt_inverse_packed_classify_kernel,
                                dim3((uint32_t)((g.nblocks + kPackClassifyThreads / kWave - 1) / (kPackClassifyThreads / kWave))),
                                dim3(kPackClassifyThreads), 0, s, a);
@@ -936,8 +955,10 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
         if (wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
         const uint64_t walk_wgs = (uint64_t)((g.nblocks + 7) / 8 * 8) * ((g.seg_cap + kWalkThreads - 1) / kWalkThreads);
         if (walk_wgs > 0x7FFFFFFFull) return fail(BWTGPU_ERR_INVALID, "too many segments in one batch");
-        if (g.wide) hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint64_t>, dim3((uint32_t)walk_wgs), dim3(kWalkThreads), 0, s, a);
-        else hipLaunchKernelGGL(bwt_inverse_walk_segments_kernel<uint32_t>, dim3((uint32_t)walk_wgs), dim3(kWalkThreads), 0, s, a);
+        const uint32_t walk_grid = sparse ? (uint32_t)std::min<uint64_t>(walk_wgs, kSparseGrid) : (uint32_t)walk_wgs;
+        if (g.wide) hipLaunchKernelGGL((bwt_inverse_walk_segments_kernel<uint64_t, false>), dim3((uint32_t)walk_wgs), dim3(kWalkThreads), 0, s, a, (uint32_t)walk_wgs);
+        else if (sparse) hipLaunchKernelGGL((bwt_inverse_walk_segments_kernel<uint32_t, true>), dim3(walk_grid), dim3(kWalkThreads), 0, s, a, (uint32_t)walk_wgs);
+        else hipLaunchKernelGGL((bwt_inverse_walk_segments_kernel<uint32_t, false>), dim3(walk_grid), dim3(kWalkThreads), 0, s, a, (uint32_t)walk_wgs);
         HIP_TRY(hipGetLastError());
         // many segments per block, or few blocks (the chain following is then the whole cost): the
         // records go through LDS
@@ -949,11 +970,16 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
         else
             hipLaunchKernelGGL(bwt_inverse_stitch_kernel<256>, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bwt_inverse_place_kernel, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a);
+        if (sparse) hipLaunchKernelGGL(bwt_inverse_place_kernel<true>, dim3((uint32_t)std::min<uint64_t>(wgs, kSparseGrid)), dim3(kSegThreads), 0, s, a, (uint32_t)wgs);
+        else hipLaunchKernelGGL(bwt_inverse_place_kernel<false>, dim3((uint32_t)wgs), dim3(kSegThreads), 0, s, a, (uint32_t)wgs);
         HIP_TRY(hipGetLastError());
     }
     if (d_orig_ptr) {
         hipLaunchKernelGGL(bwt_inverse_origin_finish_kernel, dim3((uint32_t)g.nblocks), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (a.packed_first && a.left_hint) {
+        hipLaunchKernelGGL(bwt_inverse_left_kernel, dim3(1), dim3(1), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     return BWTGPU_OK;

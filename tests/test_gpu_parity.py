@@ -149,6 +149,14 @@ def test_small_alphabet_inverse(orc):
     data = np.concatenate(parts).astype(np.uint8).tobytes()
     want = orc.forward_buffer(data, bs, 4)
     assert api.inverse_batch(want[1:], bs, want[0]) == data
+    # After a batch in which every block was inverted inside LDS the library launches the table kernels
+    # as small striding grids; the next batch may need them after all: same bytes either way.
+    dna = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=6 * bs)].tobytes()
+    dna_t = orc.forward_buffer(dna, bs, 4)
+    for _ in range(2):
+        assert api.inverse_batch(dna_t[1:], bs, dna_t[0]) == dna
+        assert api.inverse_batch(want[1:], bs, want[0]) == data
+        assert api.inverse_batch(want[1:], bs, want[0]) == data
     # several LF cycles, small alphabets
     prng = random.Random(9)
     for n, sigma in [(9000, 1), (30000, 2), (70000, 4), (262145, 4)]:
