@@ -36,7 +36,12 @@ namespace bwtgpu {
 
 constexpr int kPackThreads = 1024;
 constexpr uint32_t kPackMaxRows = 262144u + 1u;  // block_size + 1 at most: the bit planes of more rows do not fit
-constexpr uint32_t kPackMinRows = 8192u;         // shorter blocks: the general kernels run several per compute unit
+// Shorter blocks are left to the table kernels, which run several per compute unit: here a block has a
+// compute unit to itself, and the end of each walk -- the last lanes finishing the longest segments --
+// does not shrink with the block.  Measured on 1 GiB of ACGT text (this kernel / table kernels):
+// 16 KiB blocks 21.6 / 11.3 ms, 32 KiB 12.9 / 11.0, 48 KiB 9.2 / 11.0, 64 KiB 7.8 / 11.0, 128 KiB 6.3 / 11.3,
+// 256 KiB 5.7 / 10.8.
+constexpr uint32_t kPackMinRows = 49152u;
 constexpr uint32_t kPackGroups = (kPackMaxRows + 63u) / 64u;  // groups of 64 rows while the delimiter row is still in
 constexpr uint32_t kPackIds = 7936u;             // segment ids (LDS holds one record each); id kPackIds = the chain's first segment
 constexpr uint32_t kPackEnd = 8191u;             // "runs into the delimiter row"
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
 
         // ---- the alphabet, from 256 bytes spread over the block (a symbol they miss shows up in the pack
         // step, which then leaves the block to the general kernels)
-        if (tid < 256) sh.lut[L[(uint32_t)tid * (n / 256u)]] = 1;
+        if (tid < 256) sh.lut[L[(uint32_t)tid * (n / 256u)]] = 1;  // n >= kPackMinRows
         __syncthreads();
         const bool present = tid < 256 && sh.lut[tid] != 0 && (uint32_t)tid != a.delim;
         const uint64_t bal = __ballot(present);
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
 #pragma unroll
         for (int i = 0; i < 5; ++i) inv *= 2u - mul * inv;
         inv &= mask;
-        const uint32_t ids = min(kPackIds, (1u << kbits) >> 4);
+        const uint32_t ids = min(kPackIds, (1u << kbits) >> 3);
         for (uint32_t i = (uint32_t)tid; i <= kPackIds; i += kPackThreads) sh.seg[i] = pack_seg(0u, kPackEnd);
         if (tid == 0) sh.ctr = 0;
         __syncthreads();

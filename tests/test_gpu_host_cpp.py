@@ -190,15 +190,15 @@ def test_cli_round_trip_around_geometry_thresholds(tmp_path, bs, nblocks):
 
 
 # DNA files through the command-line tools: the inverse takes blocks over at most four symbols
-# inside LDS when a block has 8192 .. 262145 rows (on either side the table kernels run), also for
+# inside LDS when a block has 49152 .. 262145 rows (on either side the table kernels run), also for
 # a slab pipeline whose last slab is short and for a file that mixes DNA with other bytes.
-@pytest.mark.parametrize("bs", [8190, 8191, 65536, 262144, 262145])
+@pytest.mark.parametrize("bs", [49150, 49151, 65536, 262144, 262145])
 def test_cli_dna_files(tmp_path, bs):
     import numpy as np
 
     from bwt_amd import synth
 
-    nblocks = 150 if bs < 100000 else 18
+    nblocks = 40 if bs < 100000 else 18
     total = (nblocks - 1) * bs + bs // 2 + 3
     data = synth.generate("acgt", 1000 + bs, 0, total)
     if bs == 65536:  # a stretch of ordinary bytes in the middle: those blocks go to the table kernels

@@ -125,7 +125,7 @@ def test_small_alphabet_inverse(orc):
     that mix such blocks with ordinary ones, and hand-made blocks with several LF cycles."""
     rng = np.random.default_rng(4242)
     cases = []
-    for n in [8191, 8192, 8255, 8256, 8257, 20000, 65536, 131071, 262143, 262144]:
+    for n in [49150, 49151, 49152, 49215, 49216, 49217, 65536, 131071, 262143, 262144]:
         for symbols, delim in [(b"ACGT", 0), (b"ACGT", ord("D")), (b"ACGT", 255), (b"ab", ord("a") + 3), (b"x", 7),
                                (bytes([0, 1, 2]), 3), (bytes([1, 254, 255]), 0)]:
             if n > 70000 and symbols != b"ACGT":
@@ -136,14 +136,14 @@ def test_small_alphabet_inverse(orc):
         fwd = orc.forward(data, delim)
         assert api.bwt_inverse(fwd, delim) == data, (len(data), delim)
     # delimiter row first / last: text that sorts entirely above or below the delimiter
-    for data, delim in [(b"C" * 9000, ord("A")), (b"C" * 9000, ord("T")), (b"AC" * 5000, ord("B"))]:
+    for data, delim in [(b"C" * 50000, ord("A")), (b"C" * 50000, ord("T")), (b"AC" * 26000, ord("B"))]:
         assert api.bwt_inverse(orc.forward(data, delim), delim) == data
     # a fifth symbol beyond the sampled prefix
     late = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=100000)].tobytes())
     late[77777] = ord("N")
     assert api.bwt_inverse(orc.forward(bytes(late), 0), 0) == bytes(late)
     # mixed batch: ACGT, random bytes, two symbols, ragged ACGT tail
-    bs = 40000
+    bs = 50000
     parts = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=bs)], rng.integers(1, 200, size=bs, dtype=np.uint8),
              np.frombuffer(b"AT", np.uint8)[rng.integers(0, 2, size=bs)], np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=12345)]]
     data = np.concatenate(parts).astype(np.uint8).tobytes()
@@ -159,16 +159,16 @@ def test_small_alphabet_inverse(orc):
         assert api.inverse_batch(want[1:], bs, want[0]) == data
     # several LF cycles, small alphabets
     prng = random.Random(9)
-    for n, sigma in [(9000, 1), (30000, 2), (70000, 4), (262145, 4)]:
+    for n, sigma in [(50000, 1), (60000, 2), (70000, 4), (262145, 4)]:
         blk = bytearray(prng.randrange(1, 1 + sigma) for _ in range(n))
         blk[prng.randrange(n)] = 0
         assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0), (n, sigma)
     # no delimiter / two delimiters in a small-alphabet block
-    blk = bytearray(b"ACGT" * 3000)
+    blk = bytearray(b"ACGT" * 13000)
     with pytest.raises(api.BwtGpuError):
         api.bwt_inverse(bytes(blk), 0)
     blk[5] = 0
-    blk[7000] = 0
+    blk[47000] = 0
     assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0)
 
 
