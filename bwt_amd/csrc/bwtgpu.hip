@@ -168,6 +168,17 @@ int forced_forward_path() {
     return 0;
 }
 
+// BWTGPU_INVERSE_PATH=general keeps the inverse of small-alphabet blocks on the LF-table kernels,
+// =packed lets the in-LDS inverse also take batches of few blocks (which the tiled table build serves
+// otherwise); tests run every case all three ways.
+int forced_inverse_path() {
+    const char* e = std::getenv("BWTGPU_INVERSE_PATH");
+    if (!e) return 0;
+    if (!strcmp(e, "general")) return 1;
+    if (!strcmp(e, "packed")) return 2;
+    return 0;
+}
+
 struct GridGeom {
     size_t rows;
     size_t presence_off, count_off, hist_off, rec_off, rank_off, key_off[2], id_off[2], bytes;
@@ -299,6 +310,8 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     // One workgroup builds a 1 MiB block's table in about 2 ms; with fewer blocks than compute
     // units the tables are built tile by tile instead.
     g.tiled = g.wide || (g.nblocks <= kInvTiledMaxBlocks && longest >= kInvTiledMinRows);
+    const bool pack_range = longest >= kPackMinRows && longest <= kPackMaxRows;
+    if (forced_inverse_path() == 2 && pack_range) g.tiled = false;
     g.tile_rows = (uint32_t)round_up(std::max<size_t>(4096, (longest + 255) / 256), 256);
     g.tiles_per_block = (uint32_t)((longest + g.tile_rows - 1) / g.tile_rows);
     size_t off = kHeaderBytes;
@@ -320,7 +333,7 @@ InvGeom inv_geom(const Device& d, size_t total, size_t block_size) {
     g.stage_off = take(g.split ? g.nblocks * round_up(g.seg_cap, 64) * g.slot : 0);
     g.pool_off = take(g.split ? g.nblocks * (size_t)g.chunk_cap * g.slot : 0);
     g.t_off = take((size_t)g.tstride * (g.wide ? 8 : 4) * g.nblocks);
-    g.pack_wgs = !g.tiled && longest >= kPackMinRows && longest <= kPackMaxRows ? (uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus) : 0u;
+    g.pack_wgs = !g.tiled && pack_range && forced_inverse_path() != 1 ? (uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus) : 0u;
     g.bytes = off;
     return g;
 }
@@ -911,15 +924,12 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
         return BWTGPU_OK;
     }
     // Blocks over at most four text symbols are inverted inside LDS first (bwt_inverse_packed.hpp); the
-    // kernels below then skip the blocks that kernel has finished.  BWTGPU_INVERSE_PATH=general leaves
-    // it out (tests run both ways).
+    // kernels below then skip the blocks that kernel has finished.
     a.packed_first = 0;
     a.left_hint = nullptr;
     bool sparse = false;  // the device's previous batch left nothing to the table kernels: launch them as small grids
     {
-        const char* e = std::getenv("BWTGPU_INVERSE_PATH");
-        const bool general_only = e && !strcmp(e, "general");
-        if (!general_only && g.pack_wgs && !d_orig_ptr) {
+        if (g.pack_wgs && !d_orig_ptr) {
             a.packed_first = 1;
             a.left_hint = d.inv_left_dev;
             sparse = d.inv_left && __atomic_load_n(d.inv_left, __ATOMIC_RELAXED) == 0u;

@@ -211,7 +211,7 @@ def test_cli_dna_files(tmp_path, bs):
     out = np.fromfile(f, dtype=np.uint8)
     assert out.size == total + 1 + nblocks and out[0] == 0
     _sample_blocks_equal_oracle(data, out, bs, 0, [0, 6, nblocks - 1])
-    for env in ({}, {"BWTGPU_INVERSE_PATH": "general"}):
+    for env in ({}, {"BWTGPU_INVERSE_PATH": "packed"}, {"BWTGPU_INVERSE_PATH": "general"}):
         r = subprocess.run([os.path.join(BUILD, "inverse_bwt"), f, b, str(bs)], cwd=ROOT, env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr

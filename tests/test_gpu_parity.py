@@ -35,10 +35,16 @@ def forward_path(request):
     old = os.environ.get("BWTGPU_FORWARD_PATH")
     old_inv = os.environ.get("BWTGPU_INVERSE_PATH")
     os.environ["BWTGPU_FORWARD_PATH"] = request.param
-    # the "block" runs also keep the inverse on the general kernels (no in-LDS inverse of
-    # small-alphabet blocks), so both inverse routes see every case
-    if request.param == "block":
+    # The inverse routes ride along: the "auto" runs let the in-LDS inverse of small-alphabet blocks also
+    # take batches of few blocks (the library gives those to the tiled table build otherwise, so a test's
+    # single blocks would never reach it), the "block" runs keep everything on the table kernels, the
+    # "grid" runs leave the choice to the library.
+    if request.param == "auto":
+        os.environ["BWTGPU_INVERSE_PATH"] = "packed"
+    elif request.param == "block":
         os.environ["BWTGPU_INVERSE_PATH"] = "general"
+    else:
+        os.environ.pop("BWTGPU_INVERSE_PATH", None)
     yield request.param
     if old is None:
         del os.environ["BWTGPU_FORWARD_PATH"]

@@ -63,7 +63,7 @@ for t in range(trials):
     mode = rng.random()
     path = prng.choice(["auto", "auto", "block", "grid"])
     os.environ["BWTGPU_FORWARD_PATH"] = path
-    os.environ["BWTGPU_INVERSE_PATH"] = prng.choice(["auto", "auto", "general"])  # in-LDS inverse of small alphabets, or the table kernels only
+    os.environ["BWTGPU_INVERSE_PATH"] = prng.choice(["auto", "packed", "general"])  # in-LDS inverse of small alphabets (also for few blocks), or the table kernels only
     if 0.05 <= big < 0.10:
         bs = n // rng.randrange(270, 280)
         try:
