@@ -155,6 +155,10 @@ def test_small_alphabet_inverse(orc):
     data = np.concatenate(parts).astype(np.uint8).tobytes()
     want = orc.forward_buffer(data, bs, 4)
     assert api.inverse_batch(want[1:], bs, want[0]) == data
+    # a ragged last block that is itself long enough for the in-LDS path (its own cut map and sizes)
+    rag = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=2 * 70000 + 60001)].tobytes()
+    rag_t = orc.forward_buffer(rag, 70000, 4)
+    assert api.inverse_batch(rag_t[1:], 70000, rag_t[0]) == rag
     # After a batch in which every block was inverted inside LDS the library launches the table kernels
     # as small striding grids; the next batch may need them after all: same bytes either way.
     dna = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=6 * bs)].tobytes()
@@ -176,6 +180,24 @@ def test_small_alphabet_inverse(orc):
     blk[5] = 0
     blk[47000] = 0
     assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0)
+
+
+def test_small_alphabet_many_blocks(orc):
+    """More DNA blocks than compute units (the in-LDS inverse works through a list of blocks per
+    workgroup), every 37th block ordinary bytes (left to the table kernels, which skip the finished
+    blocks), a ragged last block that is still long enough for the in-LDS path, and a second batch
+    with a different last block through the same library state."""
+    rng = np.random.default_rng(777)
+    bs = 49152
+    for nblocks, tail in [(300, 49100), (270, 20000)]:
+        total = (nblocks - 1) * bs + tail
+        data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=total)].copy()
+        for b in range(5, nblocks - 1, 37):
+            data[b * bs:(b + 1) * bs] = rng.integers(1, 250, size=bs, dtype=np.uint8)
+        data = data.tobytes()
+        want = orc.forward_buffer(data, bs, 8)
+        assert api.forward_batch(data, bs, want[0]) == want[1:]
+        assert api.inverse_batch(want[1:], bs, want[0]) == data, (nblocks, tail)
 
 
 def test_find_unused_byte():
