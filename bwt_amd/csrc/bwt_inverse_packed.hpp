@@ -25,7 +25,8 @@
 //            segment run into}
 //   order    pointer jumping over the records: bytes from a segment's start to the text's start
 //   walk 2   the same walks again, now writing bytes (back to front, a dword every four steps) to
-//            where the order step says they go; the long segments are handed out first
+//            where the order step says they go; the segments are handed out stretch by stretch of
+//            the text, the long ones of a stretch first
 // The result is the chain the reference walks (src/inverse_bwt.cpp:48-62), byte for byte; a
 // hand-made block whose LF permutation has several cycles yields the cycle through the delimiter
 // row, like the reference, with the shorter length in lens[].
