@@ -207,7 +207,7 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
             const uint32_t img = __umul24(q, mul) & mask;
             const bool at_end = row == drow, cut = img < ids;
             hit_next = at_end ? kPackEnd : img;
-            walking = at_end | cut ? 0u : ~0u;
+            walking = (at_end | cut) ? 0u : ~0u;
         }
         if (EMIT && (it & 3u) == 3u && cnt >= 4u) store_dword();  // (it & 3) is wave-uniform: a lane holds at most 7 bytes
     }
