@@ -56,7 +56,7 @@ struct FwdArgs {
     uint64_t ws_stride;
     uint32_t* queue;      // [0] next block index to hand out, [1] error flags, [2] blocks put off, [3] next put-off
                           // block to hand out, [4] next entry of `normal` to hand out, [5] entries of `normal`,
-                          // [6] next block to classify, [16..] phase clocks
+                          // [6] next block to classify, [7] next block for the text-in-LDS launch, [16..] phase clocks
     uint32_t* deferred;   // nblocks words: the blocks the first launch put off for the second
     uint32_t* normal;     // nblocks words: with a classifying launch first, the blocks it leaves to the first launch
 };

@@ -1,0 +1,614 @@
+// bwt_forward_lds.hpp -- forward BWT of blocks whose packed text fits LDS.
+//
+// Replaces, for the blocks it takes, build_suffix_array and bwt_forward of the reference
+// (src/bwt.cpp:50-99, :102-123) like bwt_forward.hpp does; the bytes are the same because the suffix
+// array of a string is unique.  The general kernel (bwt_forward.hpp) moves an 8-byte element per
+// suffix through HBM and sorts 64-bit words in LDS because the block's text stays in device memory:
+// everything a later step wants to know about a suffix has to ride along in its element.  Here the
+// text itself is resident in LDS -- two bits per symbol for blocks over at most four text symbols
+// (256 KiB of DNA is 64 KB), whole bytes for blocks of at most 64 KiB -- so a suffix is just its
+// position: any 32-bit window of the text (16 two-bit symbols, or 4 bytes) is two LDS reads and a
+// funnel shift away, and the byte that precedes a suffix is one more read.
+//
+// One workgroup of 1024 lanes per block (the text fills the compute unit's LDS), blocks from a queue:
+//   sample     16 bytes per lane spread over the block name the alphabet (2 bits per symbol if at most
+//              four values occur, else bytes if the block is short enough, else the block is left to
+//              the general kernel); a symbol the sample missed shows up in the pack step
+//   pack       text -> sh.text, big-endian inside 32-bit words so that windows compare like strings;
+//              behind the text follow "virtual" symbols that stand for the appended delimiter
+//   count      every suffix's window -> fine bin (top 13 bits) -> LDS histogram
+//   assign     prefix sum of the bins; consecutive bins form buckets of about 256 suffixes (at most
+//              1024 buckets: lane t owns bucket t)
+//   partition  tiles of 16384 positions: bucket and slot of every suffix (one LDS add-with-return),
+//              the tile grouped by bucket in LDS, written to the block's slice of HBM scratch in runs
+//   sort       a bucket is one wave's business, no workgroup barrier: its positions come back from
+//              HBM, are counted into 512 sub-bins of the bucket's key range, scattered in LDS as
+//              (key bits below the bucket's base << 9 | index), finished by a few odd-even
+//              transposition passes (sub-bins hold a handful of elements), and lane d of the wave
+//              writes the byte that precedes the d-th suffix of the bucket: the output is coalesced.
+//              Suffixes whose kept key bits tie are compared window by window through the text.
+//
+// Order.  The reference compares suffixes of text + delimiter by unsigned byte value, a suffix that
+// ends being smaller than any continuation (src/bwt.cpp:66-80); with a delimiter that does not occur
+// in the text no comparison ever gets past the delimiter.  Windows see the delimiter as a virtual
+// symbol at position len: the code of the smallest text symbol above it, followed by the smallest
+// code (or, when the delimiter is above every text symbol, the largest code throughout).  Numeric
+// order of windows then is the order of the strings wherever two windows differ, and two EQUAL windows
+// of which one contains position len are told apart by position: the suffix nearer the end reaches
+// the delimiter first, which makes it the smaller one (the larger one if the delimiter is above).
+//
+// A block is given up (left to the general kernel through the list it takes its work from) when the
+// sample or the pack step meets a fifth symbol or the delimiter inside the text, when a bucket or a
+// sub-bin is overfull (skewed keys: text, runs), or when two suffixes agree over kLdsDepth windows
+// (long repeats); what it has written by then is overwritten.
+#pragma once
+#include "bwt_forward.hpp"
+
+namespace bwtgpu {
+
+constexpr int kLdsThreads = 1024;
+constexpr int kLdsWaves = kLdsThreads / kWave;
+constexpr uint32_t kLdsMaxLen2 = 262144u;        // two bits per symbol: 64 KB of packed text
+constexpr uint32_t kLdsMaxLen8 = 65536u;         // bytes
+constexpr uint32_t kLdsMinLen = 16384u;          // shorter blocks: the general kernels run several per compute unit
+constexpr uint32_t kLdsTextWords = 16384u + 8u;  // the text, the virtual symbols behind it, and what a window there reads
+constexpr int kLdsFineBits = 13;
+constexpr uint32_t kLdsFine = 1u << kLdsFineBits;
+constexpr int kLdsFineShift = 32 - kLdsFineBits;
+constexpr uint32_t kLdsBuckets = kLdsThreads;    // lane t owns bucket t in the assign and partition steps
+constexpr uint32_t kLdsTarget = 256;             // suffixes per bucket the assign step aims at
+constexpr uint32_t kLdsCap = 512;                // ... and the most a bucket may hold
+constexpr int kLdsSubBits = 9;
+constexpr uint32_t kLdsSub = 1u << kLdsSubBits;  // sub-bins of a bucket
+constexpr int kLdsFieldBits = 32 - kLdsSubBits;  // key bits an element keeps (beside its 9-bit index)
+constexpr uint32_t kLdsMaxBin = 24;              // a fuller sub-bin gives the block up
+constexpr uint32_t kLdsGroup = 16;               // consecutive positions one lane handles in a sweep
+constexpr uint32_t kLdsTile = kLdsGroup * kLdsThreads;
+constexpr int kLdsPosBits = 19;                  // positions 0 .. 262144
+constexpr int kLdsDepth = 8;                     // windows two suffixes are compared over before the block is given up
+constexpr int kLdsClockSlot = 32;                // phase clocks: u64 words from queue + 2 * kLdsClockSlot
+
+struct LdsWaveArea {
+    uint32_t sorted[kLdsCap];      // the bucket's elements in sub-bin order, then in order
+    uint32_t cnt[kLdsSub + 8];     // sub-bin counters, then their starts; after the scatter: position by index
+};
+
+struct LdsShared {
+    uint32_t text[kLdsTextWords];
+    union {
+        uint32_t fine[kLdsFine];                     // count, assign
+        struct {
+            uint32_t stage[kLdsTile];                // position | bucket << kLdsPosBits, grouped by bucket
+            uint16_t lut[kLdsFine];                  // fine bin -> bucket (beyond `fine`, which the assign step still reads)
+            uint32_t tcnt[kLdsBuckets];              // per tile: elements per bucket
+            uint32_t tstart[kLdsBuckets];            // per tile: where the bucket's run starts in `stage`
+            uint32_t delta[kLdsBuckets];             // per tile: scratch slot of the run's first element minus its stage index
+        } part;
+        struct {
+            LdsWaveArea wave[kLdsWaves];
+            uint32_t dstart[kLdsBuckets + 1];        // first row of every bucket
+            uint16_t dflo[kLdsBuckets + 2];          // first fine bin of every bucket
+        } sort;
+    } u;
+    uint8_t present[256];
+    uint8_t code[256];             // byte -> code 0..3; 0x80: not in the alphabet (the delimiter included)
+    uint32_t wsum[kLdsWaves];
+    uint64_t ball[4];
+    uint32_t cb[4];                // code -> byte
+    uint32_t blk, bad, next;
+};
+static_assert(sizeof(LdsShared) <= 160u * 1024u, "one workgroup's LDS");
+
+struct __attribute__((packed, aligned(1))) LdsBytes16 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+    v = max(v, dpp_or_zero<0x111, 0xF>(v));
+    v = max(v, dpp_or_zero<0x112, 0xF>(v));
+    v = max(v, dpp_or_zero<0x114, 0xF>(v));
+    v = max(v, dpp_or_zero<0x118, 0xF>(v));
+    v = max(v, dpp_or_zero<0x142, 0xA>(v));
+    v = max(v, dpp_or_zero<0x143, 0xC>(v));
+    return wave_read(v, kWave - 1);
+}
+
+// Keeps the accesses of one wave's lanes to the wave's own LDS area in program order: lanes hand values
+// to each other through that area without a workgroup barrier (a wave's LDS instructions execute in order).
+__device__ __forceinline__ void wave_sync() {
+    compiler_fence();
+    __builtin_amdgcn_wave_barrier();
+    compiler_fence();
+}
+
+template <int BITS>
+struct LdsFmt {
+    static constexpr int kPerWord = 32 / BITS;                  // symbols per 32-bit word
+    static constexpr int kWordShift = BITS == 2 ? 4 : 2;        // log2(kPerWord)
+    static constexpr int kGroupWords = (int)kLdsGroup / kPerWord;  // words that hold a lane's 16 positions
+};
+
+// The 32-bit window that starts at symbol p (p <= len: the words behind the text hold the virtual symbols).
+template <int BITS>
+__device__ __forceinline__ uint32_t lds_window(const uint32_t* text, uint32_t p) {
+    constexpr int WS = LdsFmt<BITS>::kWordShift;
+    const uint32_t w = p >> WS, s = (p & ((1u << WS) - 1u)) * (uint32_t)BITS;
+    const uint64_t both = ((uint64_t)text[w] << 32) | text[w + 1u];
+    return (uint32_t)((both << s) >> 32);
+}
+
+// The windows of the 16 positions 16 g .. 16 g + 15.
+template <int BITS>
+__device__ __forceinline__ void lds_group_windows(const uint32_t* text, uint32_t g, uint32_t (&key)[kLdsGroup]) {
+    constexpr int GW = LdsFmt<BITS>::kGroupWords, PW = LdsFmt<BITS>::kPerWord;
+    uint32_t w[GW + 1];
+#pragma unroll
+    for (int i = 0; i <= GW; ++i) w[i] = text[g * (uint32_t)GW + (uint32_t)i];
+#pragma unroll
+    for (int j = 0; j < (int)kLdsGroup; ++j) {
+        const int q = j / PW, r = (j % PW) * BITS;
+        key[j] = r ? __builtin_amdgcn_alignbit(w[q], w[q + 1], 32 - r) : w[q];
+    }
+}
+
+// The byte before suffix p (the delimiter before suffix 0): what the suffix's row of the transform holds.
+template <int BITS>
+__device__ __forceinline__ uint32_t lds_prev_byte(const uint32_t* text, uint32_t p, uint32_t cbytes, uint32_t delim) {
+    constexpr int WS = LdsFmt<BITS>::kWordShift;
+    const uint32_t q = p - 1u;
+    const uint32_t word = text[(p ? q : 0u) >> WS];
+    const uint32_t sym = (word >> (32u - (uint32_t)BITS - (q & ((1u << WS) - 1u)) * (uint32_t)BITS)) & ((1u << BITS) - 1u);
+    const uint32_t byte = BITS == 8 ? sym : (cbytes >> (8u * sym)) & 255u;
+    return p ? byte : delim;
+}
+
+// Whether suffix p sorts before suffix q (p != q), window by window.  `above`: the delimiter is above
+// every text symbol.  Sets *unresolved when kLdsDepth windows do not tell them apart.
+template <int BITS>
+__device__ __forceinline__ bool lds_suffix_less(const uint32_t* text, uint32_t p, uint32_t q, uint32_t len, bool above,
+                                                bool* unresolved) {
+    constexpr uint32_t K = LdsFmt<BITS>::kPerWord;
+#pragma unroll 1
+    for (int k = 0; k < kLdsDepth; ++k) {
+        const uint32_t a = lds_window<BITS>(text, p), b = lds_window<BITS>(text, q);
+        if (a != b) return a < b;
+        if (max(p, q) + K > len) return above ? p < q : p > q;  // one of the equal windows holds the delimiter
+        p += K;
+        q += K;
+    }
+    *unresolved = true;
+    return p < q;
+}
+
+// One block.  Returns false when the block is given up (workgroup-uniform).
+template <int BITS>
+__device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
+                                                  uint8_t* __restrict__ out, uint32_t* sa, LdsShared& sh, uint32_t sigma,
+                                                  uint32_t dr, uint32_t cbytes, PhaseClock& pc) {
+    constexpr int PW = LdsFmt<BITS>::kPerWord, WS = LdsFmt<BITS>::kWordShift;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t n = len + 1u;
+    const bool above = BITS == 2 && dr == sigma;
+    const uint32_t top = (1u << BITS) - 1u;
+    // the virtual symbols at position len and behind it
+    const uint32_t vd = BITS == 8 ? delim : above ? top : dr, vfill = above ? top : 0u;
+    const uint32_t nwords = (len >> WS) + 3u;  // a window at position len reads the word of len and the next one
+
+    // ---- pack ----------------------------------------------------------------------------------
+    for (uint32_t i = (uint32_t)tid; i < kLdsFine; i += kLdsThreads) sh.u.fine[i] = 0;
+    {
+        uint32_t flags = 0;
+        constexpr uint32_t kWordsPer16 = 16u / (uint32_t)PW;  // words a 16-byte load fills: 1 or 4
+        const uint32_t nvec = (nwords + kWordsPer16 - 1u) / kWordsPer16;
+        constexpr int U = 4;
+        for (uint32_t v0 = (uint32_t)tid; v0 < nvec; v0 += U * kLdsThreads) {
+            uint32_t d[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t v = v0 + (uint32_t)u * kLdsThreads, p0 = 16u * v;
+                d[u][0] = d[u][1] = d[u][2] = d[u][3] = 0;
+                if (v < nvec && p0 + 16u <= len) {
+                    const LdsBytes16 x = *reinterpret_cast<const LdsBytes16*>(s + p0);
+                    d[u][0] = x.x; d[u][1] = x.y; d[u][2] = x.z; d[u][3] = x.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t v = v0 + (uint32_t)u * kLdsThreads, p0 = 16u * v;
+                if (v >= nvec) continue;
+                if (p0 + 16u > len) {  // the block's ragged end and the virtual symbols: byte by byte
+#pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) {
+                        const uint32_t p = p0 + k;
+                        uint32_t byte;
+                        if (p < len) {
+                            byte = s[p];
+                            if (BITS == 8 && byte == delim) flags |= 0x80u;
+                        } else if (BITS == 8) {
+                            byte = p == len ? vd : vfill;
+                        } else {
+                            byte = cbytes & 255u;  // any text symbol: replaced below
+                        }
+                        d[u][k >> 2] |= byte << (8u * (k & 3u));
+                    }
+                }
+                if (BITS == 8) {
+                    uint32_t wd[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        wd[k] = __builtin_bswap32(d[u][k]);
+                        if (p0 + 16u <= len) {  // a zero byte of x ^ delimiter: the delimiter occurs in the text
+                            const uint32_t x = d[u][k] ^ (delim * 0x01010101u);
+                            flags |= ((x - 0x01010101u) & ~x & 0x80808080u) ? 0x80u : 0u;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4u * v + (uint32_t)k < kLdsTextWords) sh.text[4u * v + (uint32_t)k] = wd[k];
+                } else {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) {
+                        uint32_t c = sh.code[(d[u][k >> 2] >> (8u * (k & 3u))) & 255u];
+                        const uint32_t p = p0 + k;
+                        if (p0 + 16u > len && p >= len) c = p == len ? vd : vfill;
+                        flags |= c;
+                        word |= (c & 3u) << (30u - 2u * k);
+                    }
+                    sh.text[v] = word;
+                }
+            }
+        }
+        if (flags & 0x80u) sh.bad = 1;
+    }
+    __syncthreads();
+    if (sh.bad) return false;  // workgroup-uniform
+    pc.lap(kLdsClockSlot + 1);
+
+    // ---- count: fine bin of every suffix ---------------------------------------------------------
+    const uint32_t ngroups = (n + kLdsGroup - 1u) / kLdsGroup;
+    for (uint32_t g = (uint32_t)tid; g < ngroups; g += kLdsThreads) {
+        uint32_t key[kLdsGroup];
+        lds_group_windows<BITS>(sh.text, g, key);
+        const uint32_t p0 = g * kLdsGroup;
+        if (p0 + kLdsGroup <= n) {
+#pragma unroll
+            for (int j = 0; j < (int)kLdsGroup; ++j) atomicAdd(&sh.u.fine[key[j] >> kLdsFineShift], 1u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < (int)kLdsGroup; ++j)
+                if (p0 + (uint32_t)j < n) atomicAdd(&sh.u.fine[key[j] >> kLdsFineShift], 1u);
+        }
+    }
+    __syncthreads();
+    pc.lap(kLdsClockSlot + 2);
+
+    // ---- assign: fine bins -> buckets ------------------------------------------------------------
+    // bin f goes to bucket (first slot of f) / target: buckets are runs of consecutive bins, hold less
+    // than target + (their last bin) suffixes, and there are at most 1024 of them.
+    const uint32_t target = max(kLdsTarget, (n + kLdsBuckets - 1u) / kLdsBuckets);
+    const uint32_t nb = (n - 1u) / target + 1u;
+    uint32_t my_start, my_end, my_flo;
+    {
+        const uint32_t magic = 0xFFFFFFFFu / target + 1u;
+        auto bucket_of = [&](uint32_t slot) {
+            uint32_t q = __umulhi(slot, magic);
+            if (q * target > slot) --q;
+            return min(q, kLdsBuckets - 1u);
+        };
+        constexpr int B = (int)(kLdsFine / kLdsThreads);  // 8 bins per lane
+        uint32_t c[B];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            c[i] = sh.u.fine[(uint32_t)tid * B + i];
+            sum += c[i];
+        }
+        const uint32_t before = tid ? sh.u.fine[(uint32_t)tid * B - 1u] : 0u;
+        uint32_t total;
+        uint32_t run = block_exclusive_scan<kLdsThreads>(sum, sh.wsum, total);
+        uint32_t bprev = tid ? bucket_of(run - before) : 0xFFFFFFFFu;
+        sh.u.part.tcnt[tid] = 0;
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const uint32_t f = (uint32_t)tid * B + i;
+            const uint32_t bk = bucket_of(run);
+            sh.u.part.lut[f] = (uint16_t)bk;
+            for (uint32_t k = bprev + 1u; k <= bk && bk != bprev; ++k) {  // bucket bk, and the empty ones a long bin skips
+                sh.u.part.tstart[k] = run;
+                sh.u.part.delta[k] = f;
+            }
+            bprev = bk;
+            run += c[i];
+        }
+        if (tid == kLdsThreads - 1)
+            for (uint32_t k = bprev + 1u; k < nb; ++k) {  // nothing beyond the last bin that has suffixes
+                sh.u.part.tstart[k] = n;
+                sh.u.part.delta[k] = kLdsFine;
+            }
+        __syncthreads();
+        my_start = (uint32_t)tid < nb ? sh.u.part.tstart[tid] : n;
+        my_end = (uint32_t)tid + 1u < nb ? sh.u.part.tstart[tid + 1] : n;
+        my_flo = (uint32_t)tid < nb ? sh.u.part.delta[tid] : kLdsFine;
+        if (my_end - my_start > kLdsCap) sh.bad = 1;
+        __syncthreads();
+        if (sh.bad) return false;  // workgroup-uniform: a key prefix too common for a wave's bucket
+    }
+    pc.lap(kLdsClockSlot + 3);
+
+    // ---- partition: positions into their buckets' stretches of `sa`, tile by tile ----------------------
+    {
+        uint32_t cursor = my_start;
+        const uint32_t ntiles = (n + kLdsTile - 1u) / kLdsTile;
+        for (uint32_t tile = 0; tile < ntiles; ++tile) {
+            const uint32_t g = tile * kLdsThreads + (uint32_t)tid, p0 = g * kLdsGroup;
+            uint32_t rec[kLdsGroup];  // bucket << 14 | slot among the tile's elements of that bucket
+            if (p0 < n) {
+                uint32_t key[kLdsGroup];
+                lds_group_windows<BITS>(sh.text, g, key);
+#pragma unroll
+                for (int j = 0; j < (int)kLdsGroup; ++j) {
+                    rec[j] = 0xFFFFFFFFu;
+                    if (p0 + (uint32_t)j < n) {
+                        const uint32_t bk = sh.u.part.lut[key[j] >> kLdsFineShift];
+                        rec[j] = (bk << 14) | atomicAdd(&sh.u.part.tcnt[bk], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t c = sh.u.part.tcnt[tid];
+            sh.u.part.tcnt[tid] = 0;
+            uint32_t total;
+            const uint32_t excl = block_exclusive_scan<kLdsThreads>(c, sh.wsum, total);
+            sh.u.part.tstart[tid] = excl;
+            sh.u.part.delta[tid] = cursor - excl;
+            cursor += c;
+            __syncthreads();
+            if (p0 < n) {
+#pragma unroll
+                for (int j = 0; j < (int)kLdsGroup; ++j)
+                    if (rec[j] != 0xFFFFFFFFu) {
+                        const uint32_t bk = rec[j] >> 14;
+                        sh.u.part.stage[sh.u.part.tstart[bk] + (rec[j] & 16383u)] = (p0 + (uint32_t)j) | (bk << kLdsPosBits);
+                    }
+            }
+            __syncthreads();
+            const uint32_t tcount = min(kLdsTile, n - tile * kLdsTile);
+#pragma unroll
+            for (int i = 0; i < (int)kLdsGroup; ++i) {
+                const uint32_t j = (uint32_t)i * kLdsThreads + (uint32_t)tid;
+                if (j < tcount) {
+                    const uint32_t v = sh.u.part.stage[j];
+                    store_global(sa + (sh.u.part.delta[v >> kLdsPosBits] + j), v & ((1u << kLdsPosBits) - 1u));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    pc.lap(kLdsClockSlot + 4);
+
+    // ---- sort: one wave per bucket ---------------------------------------------------------------
+    sh.u.sort.dstart[tid] = my_start;
+    sh.u.sort.dflo[tid] = (uint16_t)my_flo;
+    if (tid == 0) {
+        sh.u.sort.dstart[kLdsBuckets] = n;
+        sh.u.sort.dflo[kLdsBuckets] = (uint16_t)kLdsFine;
+        sh.next = 0;
+    }
+    __syncthreads();
+    LdsWaveArea& wa = sh.u.sort.wave[w];
+    for (;;) {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&sh.next, 1u);
+        k = wave_read(k, 0);
+        if (k >= nb || *(volatile uint32_t*)&sh.bad) break;  // wave-uniform
+        const uint32_t s0 = sh.u.sort.dstart[k], cnt = sh.u.sort.dstart[k + 1u] - s0;
+        if (cnt == 0) continue;
+        const uint32_t f0 = sh.u.sort.dflo[k], f1 = sh.u.sort.dflo[k + 1u];
+        // the bucket's keys lie in [f0 << 19, f1 << 19): kb bits hold a key's offset from the base
+        const uint32_t base = f0 << kLdsFineShift;
+        const int kb = kLdsFineShift + bit_length(f1 - f0 - 1u);
+        const int sub_shift = kb - kLdsSubBits;
+        const int field_shift = kb > kLdsFieldBits ? kb - kLdsFieldBits : 0;
+        const uint32_t nv = (cnt + (uint32_t)kWave - 1u) >> 6;
+        constexpr int V = (int)(kLdsCap / kWave);
+        // 1. counters
+        {
+            uint4* c4 = reinterpret_cast<uint4*>(wa.cnt);
+            c4[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+            c4[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        // 2. the bucket's positions
+        uint32_t pos[V], el[V], sub[V], slot[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            pos[v] = 0;
+            if ((uint32_t)v < nv) {
+                const uint32_t i = (uint32_t)(v * kWave + lane);
+                if (i < cnt) pos[v] = load_global(sa + s0 + i);
+            }
+        }
+        wave_sync();
+        // 3. sub-bin and slot
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if ((uint32_t)v < nv) {
+                const uint32_t i = (uint32_t)(v * kWave + lane);
+                const uint32_t rel = lds_window<BITS>(sh.text, pos[v]) - base;
+                sub[v] = min(rel >> sub_shift, kLdsSub - 1u);
+                el[v] = ((rel >> field_shift) << kLdsSubBits) | i;
+                slot[v] = 0;
+                if (i < cnt) slot[v] = atomicAdd(&wa.cnt[sub[v]], 1u);
+            }
+        }
+        wave_sync();
+        // 4. sub-bin starts
+        uint32_t maxbin;
+        {
+            uint4* c4 = reinterpret_cast<uint4*>(wa.cnt);
+            const uint4 a0 = c4[2 * lane], a1 = c4[2 * lane + 1];
+            const uint32_t tot = a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w;
+            const uint32_t m = max(max(max(a0.x, a0.y), max(a0.z, a0.w)), max(max(a1.x, a1.y), max(a1.z, a1.w)));
+            uint32_t run = wave_inclusive_scan(tot) - tot;
+            uint4 b0, b1;
+            b0.x = run; run += a0.x;
+            b0.y = run; run += a0.y;
+            b0.z = run; run += a0.z;
+            b0.w = run; run += a0.w;
+            b1.x = run; run += a1.x;
+            b1.y = run; run += a1.y;
+            b1.z = run; run += a1.z;
+            b1.w = run;
+            c4[2 * lane] = b0;
+            c4[2 * lane + 1] = b1;
+            maxbin = wave_max(m);
+        }
+        if (maxbin > kLdsMaxBin) {  // wave-uniform: many suffixes under one key prefix
+            if (lane == 0) sh.bad = 1;
+            break;
+        }
+        wave_sync();
+        // 5. scatter into sub-bin order; the counters' words then take the positions by index
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if ((uint32_t)v < nv) slot[v] += wa.cnt[sub[v]];
+        wave_sync();
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if ((uint32_t)v < nv) {
+                const uint32_t i = (uint32_t)(v * kWave + lane);
+                if (i < cnt) {
+                    wa.sorted[slot[v]] = el[v];
+                    wa.cnt[i] = pos[v];
+                }
+            }
+        wave_sync();
+        // 6. odd-even transposition passes: an element is at most (its sub-bin's size - 1) places from home
+        if (maxbin > 1u) {
+            for (uint32_t pass = 0; pass <= maxbin; ++pass) {
+                const uint32_t odd = pass & 1u;
+#pragma unroll
+                for (int u = 0; u < V / 2; ++u) {
+                    if ((uint32_t)(u * 2 * kWave) < cnt) {  // wave-uniform
+                        const uint32_t x = 2u * (uint32_t)(u * kWave + lane) + odd;
+                        if (x + 1u < cnt) {
+                            const uint32_t a = wa.sorted[x], b = wa.sorted[x + 1u];
+                            wa.sorted[x] = min(a, b);
+                            wa.sorted[x + 1u] = max(a, b);
+                        }
+                    }
+                }
+                wave_sync();
+            }
+        }
+        // 7. rows: lane d writes the byte before the d-th suffix of the bucket
+        bool unresolved = false;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if ((uint32_t)v < nv) {
+                const uint32_t d = (uint32_t)(v * kWave + lane);
+                if (d < cnt) {
+                    const uint32_t e = wa.sorted[d];
+                    const uint32_t after = d + 1u < cnt ? wa.sorted[d + 1u] : ~e;
+                    const uint32_t before = d ? wa.sorted[d - 1u] : ~e;
+                    const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
+                    uint32_t row = d;
+                    if ((((e ^ after) >> kLdsSubBits) == 0u) | (((e ^ before) >> kLdsSubBits) == 0u)) {
+                        // the kept key bits tie: the run's members are ordered through the text
+                        uint32_t lo = d, hi = d + 1u;
+                        while (lo > 0u && ((wa.sorted[lo - 1u] ^ e) >> kLdsSubBits) == 0u) --lo;
+                        while (hi < cnt && ((wa.sorted[hi] ^ e) >> kLdsSubBits) == 0u) ++hi;
+                        row = lo;
+                        for (uint32_t x = lo; x < hi; ++x) {
+                            const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)];
+                            if (q != p && lds_suffix_less<BITS>(sh.text, q, p, len, above, &unresolved)) ++row;
+                        }
+                    }
+                    out[s0 + row] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+                }
+            }
+        }
+        if (__ballot(unresolved) != 0ull) {  // a repeat longer than the windows looked at
+            if (lane == 0) sh.bad = 1;
+            break;
+        }
+        wave_sync();
+    }
+    __syncthreads();
+    pc.lap(kLdsClockSlot + 5);
+    return sh.bad == 0u;
+}
+
+// Blocks of kLdsMinLen .. kLdsMaxLen2 bytes from the queue (queue[7]); a block this kernel does not
+// finish is appended to a.normal (queue[5] counts), which the general kernel's next launch works through.
+__global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a) {
+    __shared__ LdsShared sh;
+    const int tid = threadIdx.x, w = wave_id();
+    uint32_t* sa = reinterpret_cast<uint32_t*>(a.ws + (uint64_t)blockIdx.x * a.ws_stride);
+    PhaseClock pc;
+    pc.start(a.queue);
+    for (;;) {
+        __syncthreads();  // everybody is done with the block before
+        if (tid == 0) {
+            sh.blk = atomicAdd(&a.queue[7], 1u);
+            sh.bad = 0;
+        }
+        if (tid < 256) sh.present[tid] = 0;
+        __syncthreads();
+        const uint32_t b = sh.blk;
+        if (b >= a.nblocks) break;
+        const uint64_t off = (uint64_t)b * a.block_size;
+        const uint64_t rem = a.total_len - off;
+        const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;
+        const uint8_t* __restrict__ s = a.in + off;
+        uint8_t* __restrict__ out = a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u);
+        bool done = false;
+        if (len >= kLdsMinLen && len <= kLdsMaxLen2) {  // workgroup-uniform
+            // ---- the alphabet, from 16 bytes per lane spread over the block
+            {
+                const uint32_t at = (uint32_t)(((uint64_t)tid * (len - 16u)) / (kLdsThreads - 1u));
+                const LdsBytes16 x = *reinterpret_cast<const LdsBytes16*>(s + at);
+                const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sh.present[(d[k >> 2] >> (8 * (k & 3))) & 255u] = 1;
+            }
+            __syncthreads();
+            const bool present = tid < 256 && sh.present[tid] != 0;
+            const uint64_t bal = __ballot(present);
+            if (w < 4 && lane_id() == 0) sh.ball[w] = bal;
+            if (tid < 4) sh.cb[tid] = 0;
+            __syncthreads();
+            uint32_t sigma = 0, below = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t c = (uint32_t)__popcll(sh.ball[i]);
+                sigma += c;
+                if (i < w) below += c;
+            }
+            const bool delim_seen = ((sh.ball[a.delim >> 6] >> (a.delim & 63u)) & 1ull) != 0ull;
+            if (!delim_seen && sigma <= 4u) {
+                if (tid < 256) {
+                    const uint32_t code = below + (uint32_t)__popcll(bal & lanemask_lt());
+                    sh.code[tid] = present ? (uint8_t)code : (uint8_t)0x80;
+                    if (present) sh.cb[code] = (uint32_t)tid;
+                }
+                __syncthreads();
+                const uint32_t cbytes = sh.cb[0] | (sh.cb[1] << 8) | (sh.cb[2] << 16) | (sh.cb[3] << 24);
+                uint32_t dr = 0;  // text symbols below the delimiter
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) dr += (i < sigma && ((cbytes >> (8u * i)) & 255u) < a.delim) ? 1u : 0u;
+                pc.lap(kLdsClockSlot + 0);
+                done = lds_forward_block<2>(s, len, a.delim, out, sa, sh, sigma, dr, cbytes, pc);
+            } else if (!delim_seen && len <= kLdsMaxLen8) {
+                pc.lap(kLdsClockSlot + 0);
+                done = lds_forward_block<8>(s, len, a.delim, out, sa, sh, 256u, a.delim, 0u, pc);
+            }
+        }
+        if (tid == 0) {
+            if (!done) a.normal[atomicAdd(&a.queue[5], 1u)] = b;
+        }
+        pc.count(kLdsClockSlot + (done ? 6 : 7), 1);
+    }
+}
+
+}  // namespace bwtgpu

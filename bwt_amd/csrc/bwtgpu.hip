@@ -13,6 +13,7 @@
 
 #include "bwt_forward.hpp"
 #include "bwt_forward_grid.hpp"
+#include "bwt_forward_lds.hpp"
 #include "bwt_forward_small.hpp"
 #include "bwt_inverse.hpp"
 #include "bwt_inverse_small.hpp"
@@ -27,7 +28,7 @@ constexpr int kFwdWideThreads = 1024;  // forward, few-block inputs: one workgro
 constexpr size_t kWideMinBlock = 8192; // shorter blocks do not pay for the wide workgroup
 constexpr int kFwdThreads = 256;   // forward: threads per workgroup (4 waves, each with an 8 KiB LDS staging tile)
 constexpr int kInvThreads = 256;   // inverse table build: threads per workgroup
-constexpr size_t kHeaderBytes = 256;  // workspace header: work queue + status words
+constexpr size_t kHeaderBytes = 512;  // workspace header: work queue, status words, phase clocks
 constexpr size_t kBlockKernelMaxBlock = 2097151;  // forward: blocks above this only take the device-wide path
 constexpr size_t kInvTiledMaxBlocks = 128;   // inverse: batches of at most this many blocks ...
 constexpr size_t kInvTiledMinRows = 16384;   // ... of at least this many rows build their LF tables tile by tile
@@ -166,6 +167,12 @@ int forced_forward_path() {
     if (!strcmp(e, "grid")) return 1;
     if (!strcmp(e, "block")) return 2;
     return 0;
+}
+
+// BWTGPU_FORWARD_LDS=0 keeps every block on the general batch kernels (tests run both ways).
+bool forward_lds_enabled() {
+    const char* e = std::getenv("BWTGPU_FORWARD_LDS");
+    return !(e && !strcmp(e, "0"));
 }
 
 // BWTGPU_INVERSE_PATH=general keeps the inverse of small-alphabet blocks on the LF-table kernels,
@@ -636,12 +643,20 @@ int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_
     a.queue = (uint32_t*)ws;
     a.deferred = (uint32_t*)(ws + kHeaderBytes + g.stride * g.grid);
     a.normal = a.deferred + round_up(g.nblocks * 4, 256) / 4;
+    // Blocks whose packed text fits LDS (at most four text symbols up to 256 KiB, any bytes up to 64 KiB)
+    // go through bwt_forward_lds_kernel first; the blocks it does not finish are listed in a.normal, which
+    // the launches below then take their work from.
+    const bool lds_first = forward_lds_enabled() && block_size >= kLdsMinLen && block_size <= kLdsMaxLen2;
+    if (lds_first) {
+        hipLaunchKernelGGL(bwt_forward_lds_kernel, dim3((uint32_t)std::min<size_t>(g.grid, (size_t)d.cus)), dim3(kLdsThreads), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
     if (block_size + 1 <= (size_t)kSmallCap) {  // small blocks: one wave per block, everything in LDS
         const size_t wgs = (g.nblocks + kSmallWaves - 1) / kSmallWaves;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min(wgs, (size_t)d.cus * 3));
         hipLaunchKernelGGL(bwt_forward_small_kernel, dim3(grid), dim3(kSmallWaves * kWave), 0, s, a);
     } else if (g.wide) {
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, false>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, false>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, lds_first ? 2 : 0);
         hipLaunchKernelGGL((bwt_forward_kernel<kFwdWideThreads, true>), dim3(g.grid), dim3(kFwdWideThreads), 0, s, a, 1);
     } else {
         // the common case first; the blocks it puts off (periodic runs, dominant keys) in a second
@@ -655,7 +670,7 @@ int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_
         // long blocks: whole-block periods are looked for up front (bwt_forward_classify_kernel)
         const bool classify = block_size >= kClassifyMinBlock;
         if (classify) hipLaunchKernelGGL(bwt_forward_classify_kernel<256>, dim3((uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus * 8)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, classify ? 2 : 0);
+        hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, classify || lds_first ? 2 : 0);
         // debugging aid: BWTGPU_PHASES=second makes the phase clocks in the header cover the second launch only
         static const bool second_only = std::getenv("BWTGPU_PHASES") && !strcmp(std::getenv("BWTGPU_PHASES"), "second");
         if (second_only) HIP_TRY(hipMemsetAsync(ws + 64, 0, kHeaderBytes - 64, s));

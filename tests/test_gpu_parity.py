@@ -28,13 +28,20 @@ def gpu():
     yield
 
 
-@pytest.fixture(autouse=True, params=["auto", "block", "grid"])
+@pytest.fixture(autouse=True, params=["auto", "block", "grid", "lds"])
 def forward_path(request):
-    """Every test runs three times: with the library choosing between the batch kernels and the
-    device-wide forward path by the shape of the input, and with either one forced."""
+    """Every test runs four times: with the library choosing between the batch kernels and the
+    device-wide forward path by the shape of the input, with either one forced ("block": the general
+    batch kernels only), and with the batch kernels forced and the text-in-LDS kernel in front of them
+    ("lds": the library puts it there by itself, but small test inputs would take the device-wide path)."""
     old = os.environ.get("BWTGPU_FORWARD_PATH")
     old_inv = os.environ.get("BWTGPU_INVERSE_PATH")
-    os.environ["BWTGPU_FORWARD_PATH"] = request.param
+    old_lds = os.environ.get("BWTGPU_FORWARD_LDS")
+    os.environ["BWTGPU_FORWARD_PATH"] = "block" if request.param == "lds" else request.param
+    if request.param == "block":
+        os.environ["BWTGPU_FORWARD_LDS"] = "0"
+    else:
+        os.environ.pop("BWTGPU_FORWARD_LDS", None)
     # The inverse routes ride along: the "auto" runs let the in-LDS inverse of small-alphabet blocks also
     # take batches of few blocks (the library gives those to the tiled table build otherwise, so a test's
     # single blocks would never reach it), the "block" runs keep everything on the table kernels, the
@@ -50,6 +57,10 @@ def forward_path(request):
         del os.environ["BWTGPU_FORWARD_PATH"]
     else:
         os.environ["BWTGPU_FORWARD_PATH"] = old
+    if old_lds is None:
+        os.environ.pop("BWTGPU_FORWARD_LDS", None)
+    else:
+        os.environ["BWTGPU_FORWARD_LDS"] = old_lds
     if old_inv is None:
         os.environ.pop("BWTGPU_INVERSE_PATH", None)
     else:
@@ -180,6 +191,97 @@ def test_small_alphabet_inverse(orc):
     blk[5] = 0
     blk[47000] = 0
     assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0)
+
+
+def test_text_in_lds_forward(orc, forward_path):
+    """Blocks the text-in-LDS forward kernel takes (at most four text symbols up to 256 KiB, any bytes
+    up to 64 KiB): every alphabet size, the delimiter below / between / above the symbols, lengths
+    around the limits and around multiples of 16 positions, runs of the smallest and the largest
+    symbol before the delimiter (equal windows that are told apart by position), repeats longer than
+    one window and longer than the kernel compares (the block then falls back), a fifth symbol the
+    sample misses, skewed keys, batches that mix all of it with a ragged tail."""
+    if forward_path in ("grid", "block"):
+        pytest.skip("the text-in-LDS kernel is not on this route")
+    rng = np.random.default_rng(31337)
+    cases = []
+
+    def draw(symbols, n):
+        return np.frombuffer(bytes(symbols), np.uint8)[rng.integers(0, len(symbols), size=n)]
+
+    for n in [16384, 16385, 16399, 16400, 16401, 20000, 65535, 65536, 65537, 131072, 262143, 262144]:
+        for symbols, delim in [(b"ACGT", 0), (b"ACGT", ord("D")), (b"ACGT", ord("H")), (b"ACGT", 255), (b"ab", ord("a") + 3),
+                               (b"ab", 0), (b"x", 7), (b"x", 200), (bytes([0, 1, 2]), 3), (bytes([1, 254, 255]), 0),
+                               (bytes([1, 254, 255]), 100)]:
+            if n > 70000 and symbols not in (b"ACGT", b"ab"):
+                continue
+            cases.append((draw(symbols, n), delim))
+    # bytes: uniform, few values, with the delimiter just below / above / between
+    for n in [16384, 30000, 65535, 65536]:
+        cases.append((rng.integers(0, 255, size=n, dtype=np.uint8), 255))
+        cases.append((rng.integers(1, 256, size=n, dtype=np.uint8), 0))
+        cases.append((rng.integers(0, 100, size=n, dtype=np.uint8) * 2, 101))  # the delimiter between the byte values
+        cases.append((rng.integers(0, 6, size=n, dtype=np.uint8) + 10, 200))    # six values: bytes, skewed keys
+        cases.append((rng.integers(0, 6, size=n, dtype=np.uint8) + 10, 12))     # the delimiter occurs in the text
+    # runs before the delimiter: the last windows hold virtual symbols
+    for symbols, delim in [(b"ACGT", 0), (b"ACGT", 255), (b"ACGT", ord("D")), (b"ab", 0), (b"ab", 255)]:
+        for run_sym in (min(symbols), max(symbols)):
+            for run in (1, 15, 16, 17, 40, 300):
+                a = draw(symbols, 40000).copy()
+                a[-run:] = run_sym
+                cases.append((a, delim))
+    for delim in (0, 255, 128):
+        for run_val, run in [(1, 3), (1, 9), (254, 5), (127, 4), (129, 4)]:
+            a = rng.integers(1, 255, size=30000, dtype=np.uint8)
+            a[a == 128] = 7
+            a[-run:] = run_val
+            cases.append((a, delim))
+    # repeats: two copies of a stretch (ties beyond one window), long enough to exceed what is compared
+    for rep in (20, 40, 100, 200, 2000):
+        a = draw(b"ACGT", 100000).copy()
+        a[70000:70000 + rep] = a[1000:1000 + rep]
+        a[99990 - rep:99990] = a[1000:1000 + rep]
+        cases.append((a, 0))
+        b = rng.integers(0, 250, size=50000, dtype=np.uint8)
+        b[30000:30000 + rep] = b[100:100 + rep]
+        cases.append((b, 255))
+    # a fifth symbol, rare
+    late = draw(b"ACGT", 100000).copy()
+    late[77777] = ord("N")
+    cases.append((late, 0))
+    # skewed: 90 % one symbol; a long run inside
+    sk = draw(b"ACGT", 200000).copy()
+    sk[rng.random(200000) < 0.9] = ord("A")
+    cases.append((sk, 0))
+    runny = draw(b"ACGT", 150000).copy()
+    runny[50000:90000] = ord("C")
+    cases.append((runny, 255))
+    for arr, delim in cases:
+        data = arr.astype(np.uint8).tobytes()
+        want = orc.forward(data, delim)
+        got = api.bwt_forward(data, delim)
+        assert got == want, (len(data), delim, sorted(set(data))[:6])
+    # batches: more blocks than the kernel has workgroups would be too slow for the oracle; a mixed
+    # batch with a ragged tail and blocks the kernel gives up
+    for bs, total in [(32768, 9 * 32768 + 17000), (65536, 5 * 65536 + 16384), (262144, 2 * 262144 + 100000)]:
+        parts = []
+        left = total
+        i = 0
+        while left > 0:
+            n = min(bs, left)
+            kind = i % 4
+            if kind == 0:
+                parts.append(draw(b"ACGT", n))
+            elif kind == 1:
+                parts.append(rng.integers(0, 250, size=n, dtype=np.uint8))
+            elif kind == 2:
+                parts.append(np.tile(np.frombuffer(b"abcdefg", np.uint8), n // 7 + 1)[:n])
+            else:
+                parts.append(draw(b"AT", n))
+            left -= n
+            i += 1
+        data = np.concatenate(parts).astype(np.uint8).tobytes()
+        want = orc.forward_buffer(data, bs, 8)
+        assert api.forward_batch(data, bs, want[0]) == want[1:], (bs, total)
 
 
 def test_small_alphabet_many_blocks(orc):
