@@ -230,6 +230,12 @@ def main() -> None:
         phase_share = {k: round(float(v) / tot, 4) for k, v in zip(names, ph) if k}
         phase_share["later_rounds_per_block"] = round(float(ph[9]) / max(1.0, float(ph[8])), 3)
         phase_share["short_stretch_given_up"] = [int(ph[21]), int(ph[22])]
+        # the text-in-LDS forward kernel's own clocks (u64 words 32.. of the header's clock area)
+        lds = d_ws_f[64 + 8 * 32:64 + 8 * 40].cpu().numpy().view("uint64").astype(float)
+        lds_tot = max(1.0, float(lds[:6].sum()))
+        for k, v in zip(["sample", "pack", "count", "assign", "partition", "sort"], lds[:6]):
+            phase_share["lds_" + k] = round(float(v) / lds_tot, 4)
+        phase_share["lds_blocks_done_given_up"] = [int(lds[6]), int(lds[7])]
         inv_clk = d_ws_i[64:64 + 128].cpu().numpy().view("uint64")  # debug builds of the library only
         if inv_clk.any():
             phase_share["inverse_stitch_clocks"] = [int(v) for v in inv_clk]

@@ -113,6 +113,14 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return wave_read(v, kWave - 1);
 }
 
+// A value the compiler has to take as new at this point: address arithmetic that depends only on the
+// thread index is otherwise computed once at the top of the kernel for every use in every phase, and
+// what does not fit the registers by then is spilled and reloaded inside the hot loops.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // Keeps the accesses of one wave's lanes to the wave's own LDS area in program order: lanes hand values
 // to each other through that area without a workgroup barrier (a wave's LDS instructions execute in order).
 __device__ __forceinline__ void wave_sync() {
@@ -186,7 +194,8 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
                                                   uint8_t* __restrict__ out, uint32_t* sa, LdsShared& sh, uint32_t sigma,
                                                   uint32_t dr, uint32_t cbytes, PhaseClock& pc) {
     constexpr int PW = LdsFmt<BITS>::kPerWord, WS = LdsFmt<BITS>::kWordShift;
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    int tid = (int)opaque(threadIdx.x);
+    const int w = wave_id();
     const uint32_t n = len + 1u;
     const bool above = BITS == 2 && dr == sigma;
     const uint32_t top = (1u << BITS) - 1u;
@@ -266,6 +275,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     pc.lap(kLdsClockSlot + 1);
 
     // ---- count: fine bin of every suffix ---------------------------------------------------------
+    tid = (int)opaque((uint32_t)tid);
     const uint32_t ngroups = (n + kLdsGroup - 1u) / kLdsGroup;
     for (uint32_t g = (uint32_t)tid; g < ngroups; g += kLdsThreads) {
         uint32_t key[kLdsGroup];
@@ -286,6 +296,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     // ---- assign: fine bins -> buckets ------------------------------------------------------------
     // bin f goes to bucket (first slot of f) / target: buckets are runs of consecutive bins, hold less
     // than target + (their last bin) suffixes, and there are at most 1024 of them.
+    tid = (int)opaque((uint32_t)tid);
     const uint32_t target = max(kLdsTarget, (n + kLdsBuckets - 1u) / kLdsBuckets);
     const uint32_t nb = (n - 1u) / target + 1u;
     uint32_t my_start, my_end, my_flo;
@@ -341,6 +352,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
         uint32_t cursor = my_start;
         const uint32_t ntiles = (n + kLdsTile - 1u) / kLdsTile;
         for (uint32_t tile = 0; tile < ntiles; ++tile) {
+            tid = (int)opaque((uint32_t)tid);
             const uint32_t g = tile * kLdsThreads + (uint32_t)tid, p0 = g * kLdsGroup;
             uint32_t rec[kLdsGroup];  // bucket << 14 | slot among the tile's elements of that bucket
             if (p0 < n) {
@@ -388,6 +400,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     pc.lap(kLdsClockSlot + 4);
 
     // ---- sort: one wave per bucket ---------------------------------------------------------------
+    tid = (int)opaque((uint32_t)tid);
     sh.u.sort.dstart[tid] = my_start;
     sh.u.sort.dflo[tid] = (uint16_t)my_flo;
     if (tid == 0) {
@@ -398,10 +411,11 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     __syncthreads();
     LdsWaveArea& wa = sh.u.sort.wave[w];
     for (;;) {
+        const int lane = (int)opaque((uint32_t)tid & 63u);
         uint32_t k = 0;
         if (lane == 0) k = atomicAdd(&sh.next, 1u);
         k = wave_read(k, 0);
-        if (k >= nb || *(volatile uint32_t*)&sh.bad) break;  // wave-uniform
+        if (k >= nb || __hip_atomic_load(&sh.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // wave-uniform
         const uint32_t s0 = sh.u.sort.dstart[k], cnt = sh.u.sort.dstart[k + 1u] - s0;
         if (cnt == 0) continue;
         const uint32_t f0 = sh.u.sort.dflo[k], f1 = sh.u.sort.dflo[k + 1u];
@@ -419,7 +433,8 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
             c4[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
         }
         // 2. the bucket's positions
-        uint32_t pos[V], el[V], sub[V], slot[V];
+        const int sub_from_el = min(kb, kLdsFieldBits);  // bits of an element's key field: its sub-bin is the top 9 of them
+        uint32_t pos[V], el[V], slot[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             pos[v] = 0;
@@ -435,10 +450,9 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
             if ((uint32_t)v < nv) {
                 const uint32_t i = (uint32_t)(v * kWave + lane);
                 const uint32_t rel = lds_window<BITS>(sh.text, pos[v]) - base;
-                sub[v] = min(rel >> sub_shift, kLdsSub - 1u);
                 el[v] = ((rel >> field_shift) << kLdsSubBits) | i;
                 slot[v] = 0;
-                if (i < cnt) slot[v] = atomicAdd(&wa.cnt[sub[v]], 1u);
+                if (i < cnt) slot[v] = atomicAdd(&wa.cnt[rel >> sub_shift], 1u);
             }
         }
         wave_sync();
@@ -471,7 +485,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
         // 5. scatter into sub-bin order; the counters' words then take the positions by index
 #pragma unroll
         for (int v = 0; v < V; ++v)
-            if ((uint32_t)v < nv) slot[v] += wa.cnt[sub[v]];
+            if ((uint32_t)v < nv) slot[v] += wa.cnt[min(el[v] >> sub_from_el, kLdsSub - 1u)];
         wave_sync();
 #pragma unroll
         for (int v = 0; v < V; ++v)
@@ -503,6 +517,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
         }
         // 7. rows: lane d writes the byte before the d-th suffix of the bucket
         bool unresolved = false;
+        uint32_t tied = 0;  // bit v: my element of vector v shares its kept key bits with a neighbour
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             if ((uint32_t)v < nv) {
@@ -512,17 +527,25 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
                     const uint32_t after = d + 1u < cnt ? wa.sorted[d + 1u] : ~e;
                     const uint32_t before = d ? wa.sorted[d - 1u] : ~e;
                     const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
-                    uint32_t row = d;
-                    if ((((e ^ after) >> kLdsSubBits) == 0u) | (((e ^ before) >> kLdsSubBits) == 0u)) {
-                        // the kept key bits tie: the run's members are ordered through the text
-                        uint32_t lo = d, hi = d + 1u;
-                        while (lo > 0u && ((wa.sorted[lo - 1u] ^ e) >> kLdsSubBits) == 0u) --lo;
-                        while (hi < cnt && ((wa.sorted[hi] ^ e) >> kLdsSubBits) == 0u) ++hi;
-                        row = lo;
-                        for (uint32_t x = lo; x < hi; ++x) {
-                            const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)];
-                            if (q != p && lds_suffix_less<BITS>(sh.text, q, p, len, above, &unresolved)) ++row;
-                        }
+                    if ((((e ^ after) >> kLdsSubBits) == 0u) | (((e ^ before) >> kLdsSubBits) == 0u)) tied |= 1u << v;
+                    else out[s0 + d] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+                }
+            }
+        }
+        if (__ballot(tied != 0u) != 0ull) {  // wave-uniform; the run's members are ordered through the text
+#pragma unroll 1
+            for (uint32_t v = 0; v < nv; ++v) {
+                if ((tied >> v) & 1u) {
+                    const uint32_t d = v * (uint32_t)kWave + (uint32_t)lane;
+                    const uint32_t e = wa.sorted[d];
+                    const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
+                    uint32_t lo = d, hi = d + 1u;
+                    while (lo > 0u && ((wa.sorted[lo - 1u] ^ e) >> kLdsSubBits) == 0u) --lo;
+                    while (hi < cnt && ((wa.sorted[hi] ^ e) >> kLdsSubBits) == 0u) ++hi;
+                    uint32_t row = lo;
+                    for (uint32_t x = lo; x < hi; ++x) {
+                        const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)];
+                        if (q != p && lds_suffix_less<BITS>(sh.text, q, p, len, above, &unresolved)) ++row;
                     }
                     out[s0 + row] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
                 }
