@@ -56,12 +56,13 @@ constexpr int kLdsFineBits = 13;
 constexpr uint32_t kLdsFine = 1u << kLdsFineBits;
 constexpr int kLdsFineShift = 32 - kLdsFineBits;
 constexpr uint32_t kLdsBuckets = kLdsThreads;    // lane t owns bucket t in the assign and partition steps
-constexpr uint32_t kLdsTarget = 256;             // suffixes per bucket the assign step aims at
+constexpr uint32_t kLdsTarget = 288;             // suffixes per bucket the assign step aims at: with fine bins of up to 32, buckets of 288 .. 320 = five full vectors
 constexpr uint32_t kLdsCap = 512;                // ... and the most a bucket may hold
 constexpr int kLdsSubBits = 9;
 constexpr uint32_t kLdsSub = 1u << kLdsSubBits;  // sub-bins of a bucket
 constexpr int kLdsFieldBits = 32 - kLdsSubBits;  // key bits an element keeps (beside its 9-bit index)
-constexpr uint32_t kLdsMaxBin = 24;              // a fuller sub-bin gives the block up
+constexpr uint32_t kLdsMaxBin = 16;              // a fuller sub-bin gives the block up (the transposition rounds below are proven up to here)
+constexpr int kLdsVecs = (int)(kLdsCap / 64u);   // 64-element vectors of the fullest bucket
 constexpr uint32_t kLdsGroup = 16;               // consecutive positions one lane handles in a sweep
 constexpr uint32_t kLdsTile = kLdsGroup * kLdsThreads;
 constexpr int kLdsPosBits = 19;                  // positions 0 .. 262144
@@ -186,6 +187,150 @@ __device__ __forceinline__ bool lds_suffix_less(const uint32_t* text, uint32_t p
     }
     *unresolved = true;
     return p < q;
+}
+
+// One bucket, by one wave: `pos` holds its cnt positions (element i in lane i % 64 of pos[i / 64]); E =
+// elements per lane once they are sorted (cnt <= 64 E, E >= 2).  The bucket's keys lie in [base, base + 2^kb).
+//   count    every element's sub-bin (the top 9 of the kb key bits below the base): LDS add-with-return
+//   scan     sub-bin starts; the fullest sub-bin tells how far an element can be from its place
+//   scatter  elements (key bits << 9 | index) into sub-bin order; the counters' words then hold the positions by index
+//   settle   lane l takes elements E l .. E l + E - 1 into registers, and rounds of compare-exchanges between
+//            neighbours -- inside the lane, then across the lane border through DPP -- finish the order.
+//            Every round applies each neighbour pair once; for sub-bins of m elements m / 2 rounds (E even) or
+//            m - 1 - (m - 1) / 4 rounds (E odd) sort every input (checked exhaustively with the 0-1 principle
+//            for all m <= 16, every E and every place a sub-bin can start).
+//   rows     element x of the bucket stands in row s0 + x: the lane stores the byte before each of its
+//            suffixes; elements whose kept key bits tie are first put in order through the text.
+template <int BITS, int E>
+__device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, const uint32_t (&pos)[kLdsVecs], int lane,
+                                                uint32_t s0, uint32_t cnt, uint32_t base, int kb, uint32_t len, bool above,
+                                                uint32_t cbytes, uint32_t delim, uint8_t* __restrict__ out, bool& give_up) {
+    static_assert(E >= 2 && E <= kLdsVecs, "elements per lane");
+    const int sub_shift = kb - kLdsSubBits;
+    const int field_bits = min(kb, kLdsFieldBits);
+    const int field_shift = kb - field_bits;
+    uint4* c4 = reinterpret_cast<uint4*>(wa.cnt);
+    c4[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+    c4[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+    wave_sync();
+    uint32_t el[E], slot[E];
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const uint32_t i = (uint32_t)(v * kWave + lane);
+        const uint32_t rel = lds_window<BITS>(sh.text, pos[v]) - base;
+        el[v] = ((rel >> field_shift) << kLdsSubBits) | i;
+        slot[v] = 0;
+        if (i < cnt) slot[v] = atomicAdd(&wa.cnt[rel >> sub_shift], 1u);
+    }
+    wave_sync();
+    uint32_t maxbin;
+    {
+        const uint4 a0 = c4[2 * lane], a1 = c4[2 * lane + 1];
+        const uint32_t tot = a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w;
+        const uint32_t m = max(max(max(a0.x, a0.y), max(a0.z, a0.w)), max(max(a1.x, a1.y), max(a1.z, a1.w)));
+        uint32_t run = wave_inclusive_scan(tot) - tot;
+        uint4 b0, b1;
+        b0.x = run; run += a0.x;
+        b0.y = run; run += a0.y;
+        b0.z = run; run += a0.z;
+        b0.w = run; run += a0.w;
+        b1.x = run; run += a1.x;
+        b1.y = run; run += a1.y;
+        b1.z = run; run += a1.z;
+        b1.w = run;
+        c4[2 * lane] = b0;
+        c4[2 * lane + 1] = b1;
+        maxbin = wave_max(m);
+    }
+    if (maxbin > kLdsMaxBin) {  // wave-uniform: many suffixes under one key prefix
+        give_up = true;
+        return;
+    }
+    wave_sync();
+#pragma unroll
+    for (int v = 0; v < E; ++v) slot[v] += wa.cnt[min(el[v] >> field_bits, kLdsSub - 1u)];
+    wave_sync();
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const uint32_t i = (uint32_t)(v * kWave + lane);
+        if (i < cnt) {
+            wa.sorted[slot[v]] = el[v];
+            wa.cnt[i] = pos[v];
+        }
+    }
+    wave_sync();
+    uint32_t a[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t x = (uint32_t)(E * lane + j);
+        const uint32_t t = wa.sorted[x];
+        a[j] = x < cnt ? t : 0xFFFFFFFFu;
+    }
+    const uint32_t rounds = maxbin > 1u ? ((E & 1) ? maxbin - 1u - (maxbin - 1u) / 4u : (maxbin + 1u) / 2u) : 0u;
+    for (uint32_t r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int j = 0; j + 1 < E; j += 2) {
+            const uint32_t lo = min(a[j], a[j + 1]), hi = max(a[j], a[j + 1]);
+            a[j] = lo;
+            a[j + 1] = hi;
+        }
+#pragma unroll
+        for (int j = 1; j + 1 < E; j += 2) {
+            const uint32_t lo = min(a[j], a[j + 1]), hi = max(a[j], a[j + 1]);
+            a[j] = lo;
+            a[j + 1] = hi;
+        }
+        const uint32_t up = wave_from_above(a[0], 0xFFFFFFFFu), dn = wave_from_below(a[E - 1], 0u);
+        a[E - 1] = min(a[E - 1], up);
+        a[0] = max(a[0], dn);
+    }
+    // elements that share their kept key bits with a neighbour
+    uint32_t tmask = 0;  // bit j: a[j] ties with its successor
+    {
+        const uint32_t nxt = wave_from_above(a[0], 0xFFFFFFFFu);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t succ = j + 1 < E ? a[j + 1 < E ? j + 1 : j] : nxt;
+            if ((((a[j] ^ succ) >> kLdsSubBits) == 0u) & ((uint32_t)(E * lane + j) + 1u < cnt)) tmask |= 1u << j;
+        }
+    }
+    const uint32_t tied = tmask | (tmask << 1) | wave_from_below((tmask >> (E - 1)) & 1u, 0u);
+    const bool any_tied = __ballot(tied != 0u) != 0ull;
+    if (any_tied) {  // wave-uniform: the tied runs are looked at in LDS
+#pragma unroll
+        for (int j = 0; j < E; ++j) wa.sorted[E * lane + j] = a[j];
+        wave_sync();
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t x = (uint32_t)(E * lane + j);
+        if (x < cnt && !((tied >> j) & 1u)) {
+            const uint32_t p = wa.cnt[a[j] & (kLdsCap - 1u)];
+            out[s0 + x] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+        }
+    }
+    if (any_tied) {
+        bool unresolved = false;
+#pragma unroll 1
+        for (uint32_t j = 0; j < (uint32_t)E; ++j) {
+            const uint32_t d = (uint32_t)(E * lane) + j;
+            if (((tied >> j) & 1u) && d < cnt) {
+                const uint32_t e = wa.sorted[d];
+                const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
+                uint32_t lo = d, hi = d + 1u;
+                while (lo > 0u && ((wa.sorted[lo - 1u] ^ e) >> kLdsSubBits) == 0u) --lo;
+                while (hi < cnt && ((wa.sorted[hi] ^ e) >> kLdsSubBits) == 0u) ++hi;
+                uint32_t row = lo;
+                for (uint32_t x = lo; x < hi; ++x) {
+                    const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)];
+                    if (q != p && lds_suffix_less<BITS>(sh.text, q, p, len, above, &unresolved)) ++row;
+                }
+                out[s0 + row] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+            }
+        }
+        if (__ballot(unresolved) != 0ull) give_up = true;  // a repeat longer than the windows looked at
+    }
+    wave_sync();
 }
 
 // One block.  Returns false when the block is given up (workgroup-uniform).
@@ -410,152 +555,57 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     }
     __syncthreads();
     LdsWaveArea& wa = sh.u.sort.wave[w];
-    for (;;) {
+    {
         const int lane = (int)opaque((uint32_t)tid & 63u);
-        uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(&sh.next, 1u);
-        k = wave_read(k, 0);
-        if (k >= nb || __hip_atomic_load(&sh.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // wave-uniform
-        const uint32_t s0 = sh.u.sort.dstart[k], cnt = sh.u.sort.dstart[k + 1u] - s0;
-        if (cnt == 0) continue;
-        const uint32_t f0 = sh.u.sort.dflo[k], f1 = sh.u.sort.dflo[k + 1u];
-        // the bucket's keys lie in [f0 << 19, f1 << 19): kb bits hold a key's offset from the base
-        const uint32_t base = f0 << kLdsFineShift;
-        const int kb = kLdsFineShift + bit_length(f1 - f0 - 1u);
-        const int sub_shift = kb - kLdsSubBits;
-        const int field_shift = kb > kLdsFieldBits ? kb - kLdsFieldBits : 0;
-        const uint32_t nv = (cnt + (uint32_t)kWave - 1u) >> 6;
-        constexpr int V = (int)(kLdsCap / kWave);
-        // 1. counters
-        {
-            uint4* c4 = reinterpret_cast<uint4*>(wa.cnt);
-            c4[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
-            c4[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        // 2. the bucket's positions
-        const int sub_from_el = min(kb, kLdsFieldBits);  // bits of an element's key field: its sub-bin is the top 9 of them
-        uint32_t pos[V], el[V], slot[V];
+        auto grab = [&]() {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&sh.next, 1u);
+            return wave_read(k, 0);
+        };
+        // the bucket's positions: element i in lane i % 64 of p[i / 64]
+        auto fetch = [&](uint32_t k, uint32_t (&p)[kLdsVecs]) {
+            const uint32_t s0 = sh.u.sort.dstart[k], cnt = sh.u.sort.dstart[k + 1u] - s0;
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            pos[v] = 0;
-            if ((uint32_t)v < nv) {
-                const uint32_t i = (uint32_t)(v * kWave + lane);
-                if (i < cnt) pos[v] = load_global(sa + s0 + i);
-            }
-        }
-        wave_sync();
-        // 3. sub-bin and slot
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            if ((uint32_t)v < nv) {
-                const uint32_t i = (uint32_t)(v * kWave + lane);
-                const uint32_t rel = lds_window<BITS>(sh.text, pos[v]) - base;
-                el[v] = ((rel >> field_shift) << kLdsSubBits) | i;
-                slot[v] = 0;
-                if (i < cnt) slot[v] = atomicAdd(&wa.cnt[rel >> sub_shift], 1u);
-            }
-        }
-        wave_sync();
-        // 4. sub-bin starts
-        uint32_t maxbin;
-        {
-            uint4* c4 = reinterpret_cast<uint4*>(wa.cnt);
-            const uint4 a0 = c4[2 * lane], a1 = c4[2 * lane + 1];
-            const uint32_t tot = a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w;
-            const uint32_t m = max(max(max(a0.x, a0.y), max(a0.z, a0.w)), max(max(a1.x, a1.y), max(a1.z, a1.w)));
-            uint32_t run = wave_inclusive_scan(tot) - tot;
-            uint4 b0, b1;
-            b0.x = run; run += a0.x;
-            b0.y = run; run += a0.y;
-            b0.z = run; run += a0.z;
-            b0.w = run; run += a0.w;
-            b1.x = run; run += a1.x;
-            b1.y = run; run += a1.y;
-            b1.z = run; run += a1.z;
-            b1.w = run;
-            c4[2 * lane] = b0;
-            c4[2 * lane + 1] = b1;
-            maxbin = wave_max(m);
-        }
-        if (maxbin > kLdsMaxBin) {  // wave-uniform: many suffixes under one key prefix
-            if (lane == 0) sh.bad = 1;
-            break;
-        }
-        wave_sync();
-        // 5. scatter into sub-bin order; the counters' words then take the positions by index
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-            if ((uint32_t)v < nv) slot[v] += wa.cnt[min(el[v] >> sub_from_el, kLdsSub - 1u)];
-        wave_sync();
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-            if ((uint32_t)v < nv) {
-                const uint32_t i = (uint32_t)(v * kWave + lane);
-                if (i < cnt) {
-                    wa.sorted[slot[v]] = el[v];
-                    wa.cnt[i] = pos[v];
+            for (int v = 0; v < kLdsVecs; ++v) {
+                p[v] = 0;
+                if ((uint32_t)(v * kWave) < cnt) {  // wave-uniform
+                    const uint32_t i = (uint32_t)(v * kWave + lane);
+                    if (i < cnt) p[v] = load_global(sa + s0 + i);
                 }
             }
-        wave_sync();
-        // 6. odd-even transposition passes: an element is at most (its sub-bin's size - 1) places from home
-        if (maxbin > 1u) {
-            for (uint32_t pass = 0; pass <= maxbin; ++pass) {
-                const uint32_t odd = pass & 1u;
+        };
+        uint32_t pos[kLdsVecs], ahead[kLdsVecs];
+        uint32_t k = grab();
+        if (k < nb) fetch(k, pos);
+        while (k < nb && !__hip_atomic_load(&sh.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {  // wave-uniform
+            const uint32_t k2 = grab();
+            if (k2 < nb) fetch(k2, ahead);  // in flight while this bucket is sorted
+            const uint32_t s0 = sh.u.sort.dstart[k], cnt = sh.u.sort.dstart[k + 1u] - s0;
+            if (cnt) {
+                const uint32_t f0 = sh.u.sort.dflo[k], f1 = sh.u.sort.dflo[k + 1u];
+                // the bucket's keys lie in [f0 << 19, f1 << 19): kb bits hold a key's offset from the base
+                const uint32_t base = f0 << kLdsFineShift;
+                const int kb = kLdsFineShift + bit_length(f1 - f0 - 1u);
+                bool give_up = false;
+                switch ((cnt + (uint32_t)kWave - 1u) >> 6) {
+                    case 1:
+                    case 2: lds_sort_bucket<BITS, 2>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                    case 3: lds_sort_bucket<BITS, 3>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                    case 4: lds_sort_bucket<BITS, 4>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                    case 5: lds_sort_bucket<BITS, 5>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                    case 6: lds_sort_bucket<BITS, 6>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                    case 7: lds_sort_bucket<BITS, 7>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                    default: lds_sort_bucket<BITS, 8>(sh, wa, pos, lane, s0, cnt, base, kb, len, above, cbytes, delim, out, give_up); break;
+                }
+                if (give_up) {  // wave-uniform
+                    if (lane == 0) sh.bad = 1;
+                    break;
+                }
+            }
+            k = k2;
 #pragma unroll
-                for (int u = 0; u < V / 2; ++u) {
-                    if ((uint32_t)(u * 2 * kWave) < cnt) {  // wave-uniform
-                        const uint32_t x = 2u * (uint32_t)(u * kWave + lane) + odd;
-                        if (x + 1u < cnt) {
-                            const uint32_t a = wa.sorted[x], b = wa.sorted[x + 1u];
-                            wa.sorted[x] = min(a, b);
-                            wa.sorted[x + 1u] = max(a, b);
-                        }
-                    }
-                }
-                wave_sync();
-            }
+            for (int v = 0; v < kLdsVecs; ++v) pos[v] = ahead[v];
         }
-        // 7. rows: lane d writes the byte before the d-th suffix of the bucket
-        bool unresolved = false;
-        uint32_t tied = 0;  // bit v: my element of vector v shares its kept key bits with a neighbour
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            if ((uint32_t)v < nv) {
-                const uint32_t d = (uint32_t)(v * kWave + lane);
-                if (d < cnt) {
-                    const uint32_t e = wa.sorted[d];
-                    const uint32_t after = d + 1u < cnt ? wa.sorted[d + 1u] : ~e;
-                    const uint32_t before = d ? wa.sorted[d - 1u] : ~e;
-                    const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
-                    if ((((e ^ after) >> kLdsSubBits) == 0u) | (((e ^ before) >> kLdsSubBits) == 0u)) tied |= 1u << v;
-                    else out[s0 + d] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
-                }
-            }
-        }
-        if (__ballot(tied != 0u) != 0ull) {  // wave-uniform; the run's members are ordered through the text
-#pragma unroll 1
-            for (uint32_t v = 0; v < nv; ++v) {
-                if ((tied >> v) & 1u) {
-                    const uint32_t d = v * (uint32_t)kWave + (uint32_t)lane;
-                    const uint32_t e = wa.sorted[d];
-                    const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
-                    uint32_t lo = d, hi = d + 1u;
-                    while (lo > 0u && ((wa.sorted[lo - 1u] ^ e) >> kLdsSubBits) == 0u) --lo;
-                    while (hi < cnt && ((wa.sorted[hi] ^ e) >> kLdsSubBits) == 0u) ++hi;
-                    uint32_t row = lo;
-                    for (uint32_t x = lo; x < hi; ++x) {
-                        const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)];
-                        if (q != p && lds_suffix_less<BITS>(sh.text, q, p, len, above, &unresolved)) ++row;
-                    }
-                    out[s0 + row] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
-                }
-            }
-        }
-        if (__ballot(unresolved) != 0ull) {  // a repeat longer than the windows looked at
-            if (lane == 0) sh.bad = 1;
-            break;
-        }
-        wave_sync();
     }
     __syncthreads();
     pc.lap(kLdsClockSlot + 5);
