@@ -70,8 +70,8 @@ constexpr int kLdsDepth = 8;                     // windows two suffixes are com
 constexpr int kLdsClockSlot = 32;                // phase clocks: u64 words from queue + 2 * kLdsClockSlot
 
 struct LdsWaveArea {
-    uint32_t sorted[kLdsCap];      // the bucket's elements in sub-bin order, then in order
-    uint32_t cnt[kLdsSub + 8];     // sub-bin counters, then their starts; after the scatter: position by index
+    uint32_t sorted[kLdsCap + kWave];  // the bucket's elements in sub-bin order, then in order (+ a slot per lane for writes that count for nothing)
+    uint32_t cnt[kLdsSub + 8];         // sub-bin counters (+ one for lanes without an element), then their starts; after the scatter: position by index
 };
 
 struct LdsShared {
@@ -214,13 +214,14 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
     c4[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
     uint32_t el[E], slot[E];
+    // (lanes without an element take part in everything, aimed at words nobody reads: no branches, so the
+    // LDS reads of all vectors are in flight together)
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const uint32_t i = (uint32_t)(v * kWave + lane);
         const uint32_t rel = lds_window<BITS>(sh.text, pos[v]) - base;
         el[v] = ((rel >> field_shift) << kLdsSubBits) | i;
-        slot[v] = 0;
-        if (i < cnt) slot[v] = atomicAdd(&wa.cnt[rel >> sub_shift], 1u);
+        slot[v] = atomicAdd(&wa.cnt[i < cnt ? rel >> sub_shift : kLdsSub], 1u);
     }
     wave_sync();
     uint32_t maxbin;
@@ -253,10 +254,8 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const uint32_t i = (uint32_t)(v * kWave + lane);
-        if (i < cnt) {
-            wa.sorted[slot[v]] = el[v];
-            wa.cnt[i] = pos[v];
-        }
+        wa.sorted[i < cnt ? slot[v] : kLdsCap + (uint32_t)lane] = el[v];
+        wa.cnt[i] = pos[v];
     }
     wave_sync();
     uint32_t a[E];
@@ -301,12 +300,17 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
         for (int j = 0; j < E; ++j) wa.sorted[E * lane + j] = a[j];
         wave_sync();
     }
+    {
+        uint32_t byte[E];
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const uint32_t x = (uint32_t)(E * lane + j);
-        if (x < cnt && !((tied >> j) & 1u)) {
-            const uint32_t p = wa.cnt[a[j] & (kLdsCap - 1u)];
-            out[s0 + x] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+        for (int j = 0; j < E; ++j) {  // (a lane's padding elements read some word of the LDS)
+            const uint32_t p = wa.cnt[a[j] & (kLdsCap - 1u)] & ((1u << kLdsPosBits) - 1u);
+            byte[j] = lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t x = (uint32_t)(E * lane + j);
+            if (x < cnt && !((tied >> j) & 1u)) out[s0 + x] = (uint8_t)byte[j];
         }
     }
     if (any_tied) {
@@ -500,7 +504,15 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
             tid = (int)opaque((uint32_t)tid);
             const uint32_t g = tile * kLdsThreads + (uint32_t)tid, p0 = g * kLdsGroup;
             uint32_t rec[kLdsGroup];  // bucket << 14 | slot among the tile's elements of that bucket
-            if (p0 < n) {
+            if (p0 + kLdsGroup <= n) {  // all of a tile's lanes but for the block's last positions
+                uint32_t key[kLdsGroup];
+                lds_group_windows<BITS>(sh.text, g, key);
+                uint32_t bk[kLdsGroup];
+#pragma unroll
+                for (int j = 0; j < (int)kLdsGroup; ++j) bk[j] = sh.u.part.lut[key[j] >> kLdsFineShift];
+#pragma unroll
+                for (int j = 0; j < (int)kLdsGroup; ++j) rec[j] = (bk[j] << 14) | atomicAdd(&sh.u.part.tcnt[bk[j]], 1u);
+            } else if (p0 < n) {
                 uint32_t key[kLdsGroup];
                 lds_group_windows<BITS>(sh.text, g, key);
 #pragma unroll
@@ -521,7 +533,13 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
             sh.u.part.delta[tid] = cursor - excl;
             cursor += c;
             __syncthreads();
-            if (p0 < n) {
+            if (p0 + kLdsGroup <= n) {
+                uint32_t at[kLdsGroup];
+#pragma unroll
+                for (int j = 0; j < (int)kLdsGroup; ++j) at[j] = sh.u.part.tstart[rec[j] >> 14] + (rec[j] & 16383u);
+#pragma unroll
+                for (int j = 0; j < (int)kLdsGroup; ++j) sh.u.part.stage[at[j]] = (p0 + (uint32_t)j) | ((rec[j] >> 14) << kLdsPosBits);
+            } else if (p0 < n) {
 #pragma unroll
                 for (int j = 0; j < (int)kLdsGroup; ++j)
                     if (rec[j] != 0xFFFFFFFFu) {
@@ -531,12 +549,23 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
             }
             __syncthreads();
             const uint32_t tcount = min(kLdsTile, n - tile * kLdsTile);
+            if (tcount == kLdsTile) {  // workgroup-uniform
+                uint32_t v[kLdsGroup], dl[kLdsGroup];
 #pragma unroll
-            for (int i = 0; i < (int)kLdsGroup; ++i) {
-                const uint32_t j = (uint32_t)i * kLdsThreads + (uint32_t)tid;
-                if (j < tcount) {
-                    const uint32_t v = sh.u.part.stage[j];
-                    store_global(sa + (sh.u.part.delta[v >> kLdsPosBits] + j), v & ((1u << kLdsPosBits) - 1u));
+                for (int i = 0; i < (int)kLdsGroup; ++i) v[i] = sh.u.part.stage[(uint32_t)i * kLdsThreads + (uint32_t)tid];
+#pragma unroll
+                for (int i = 0; i < (int)kLdsGroup; ++i) dl[i] = sh.u.part.delta[v[i] >> kLdsPosBits];
+#pragma unroll
+                for (int i = 0; i < (int)kLdsGroup; ++i)
+                    store_global(sa + (dl[i] + (uint32_t)i * kLdsThreads + (uint32_t)tid), v[i] & ((1u << kLdsPosBits) - 1u));
+            } else {
+#pragma unroll
+                for (int i = 0; i < (int)kLdsGroup; ++i) {
+                    const uint32_t j = (uint32_t)i * kLdsThreads + (uint32_t)tid;
+                    if (j < tcount) {
+                        const uint32_t v = sh.u.part.stage[j];
+                        store_global(sa + (sh.u.part.delta[v >> kLdsPosBits] + j), v & ((1u << kLdsPosBits) - 1u));
+                    }
                 }
             }
         }
