@@ -66,6 +66,8 @@ constexpr int kLdsVecs = (int)(kLdsCap / 64u);   // 64-element vectors of the fu
 constexpr uint32_t kLdsGroup = 16;               // consecutive positions one lane handles in a sweep
 constexpr uint32_t kLdsTile = kLdsGroup * kLdsThreads;
 constexpr int kLdsPosBits = 19;                  // positions 0 .. 262144
+constexpr uint32_t kLdsPosMask = (1u << 19) - 1u;
+constexpr int kLdsCodeShift = 29;                // a scratch word: position | bucket << 19 | (two-bit text) code of the symbol before << 29
 constexpr int kLdsDepth = 8;                     // windows two suffixes are compared over before the block is given up
 constexpr int kLdsClockSlot = 32;                // phase clocks: u64 words from queue + 2 * kLdsClockSlot
 
@@ -79,7 +81,7 @@ struct LdsShared {
     union {
         uint32_t fine[kLdsFine];                     // count, assign
         struct {
-            uint32_t stage[kLdsTile];                // position | bucket << kLdsPosBits, grouped by bucket
+            uint32_t stage[kLdsTile];                // scratch words (position | bucket << 19 | ...), grouped by bucket
             uint16_t lut[kLdsFine];                  // fine bin -> bucket (beyond `fine`, which the assign step still reads)
             uint32_t tcnt[kLdsBuckets];              // per tile: elements per bucket
             uint32_t tstart[kLdsBuckets];            // per tile: where the bucket's run starts in `stage`
@@ -219,7 +221,7 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const uint32_t i = (uint32_t)(v * kWave + lane);
-        const uint32_t rel = lds_window<BITS>(sh.text, pos[v]) - base;
+        const uint32_t rel = lds_window<BITS>(sh.text, pos[v] & kLdsPosMask) - base;
         el[v] = ((rel >> field_shift) << kLdsSubBits) | i;
         slot[v] = atomicAdd(&wa.cnt[i < cnt ? rel >> sub_shift : kLdsSub], 1u);
     }
@@ -304,8 +306,9 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
         uint32_t byte[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {  // (a lane's padding elements read some word of the LDS)
-            const uint32_t p = wa.cnt[a[j] & (kLdsCap - 1u)] & ((1u << kLdsPosBits) - 1u);
-            byte[j] = lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
+            const uint32_t word = wa.cnt[a[j] & (kLdsCap - 1u)];
+            if (BITS == 2) byte[j] = __builtin_amdgcn_perm(delim, cbytes, word >> kLdsCodeShift);  // codes 0 .. 3: a byte of cbytes; 4: the delimiter
+            else byte[j] = lds_prev_byte<BITS>(sh.text, word & kLdsPosMask, cbytes, delim);
         }
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -320,13 +323,13 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
             const uint32_t d = (uint32_t)(E * lane) + j;
             if (((tied >> j) & 1u) && d < cnt) {
                 const uint32_t e = wa.sorted[d];
-                const uint32_t p = wa.cnt[e & (kLdsCap - 1u)];
+                const uint32_t p = wa.cnt[e & (kLdsCap - 1u)] & kLdsPosMask;
                 uint32_t lo = d, hi = d + 1u;
                 while (lo > 0u && ((wa.sorted[lo - 1u] ^ e) >> kLdsSubBits) == 0u) --lo;
                 while (hi < cnt && ((wa.sorted[hi] ^ e) >> kLdsSubBits) == 0u) ++hi;
                 uint32_t row = lo;
                 for (uint32_t x = lo; x < hi; ++x) {
-                    const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)];
+                    const uint32_t q = wa.cnt[wa.sorted[x] & (kLdsCap - 1u)] & kLdsPosMask;
                     if (q != p && lds_suffix_less<BITS>(sh.text, q, p, len, above, &unresolved)) ++row;
                 }
                 out[s0 + row] = (uint8_t)lds_prev_byte<BITS>(sh.text, p, cbytes, delim);
@@ -503,24 +506,34 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
         for (uint32_t tile = 0; tile < ntiles; ++tile) {
             tid = (int)opaque((uint32_t)tid);
             const uint32_t g = tile * kLdsThreads + (uint32_t)tid, p0 = g * kLdsGroup;
-            uint32_t rec[kLdsGroup];  // bucket << 14 | slot among the tile's elements of that bucket
-            if (p0 + kLdsGroup <= n) {  // all of a tile's lanes but for the block's last positions
+            // per position: tag = bucket << 19 (| for two-bit text: code of the symbol before it << 29, 4 = none:
+            // position 0) and the slot among the tile's elements of that bucket; 0xFFFFFFFF: no position
+            uint32_t tag[kLdsGroup], slot[kLdsGroup];
+            if (p0 < n) {
                 uint32_t key[kLdsGroup];
                 lds_group_windows<BITS>(sh.text, g, key);
-                uint32_t bk[kLdsGroup];
+                uint32_t before = 0;  // the symbol before position p0
+                if (BITS == 2) before = g ? (sh.text[g - 1u] & 3u) << kLdsCodeShift : 4u << kLdsCodeShift;
+                if (p0 + kLdsGroup <= n) {  // all of a tile's lanes but for the block's last positions
 #pragma unroll
-                for (int j = 0; j < (int)kLdsGroup; ++j) bk[j] = sh.u.part.lut[key[j] >> kLdsFineShift];
+                    for (int j = 0; j < (int)kLdsGroup; ++j) tag[j] = sh.u.part.lut[key[j] >> kLdsFineShift];
 #pragma unroll
-                for (int j = 0; j < (int)kLdsGroup; ++j) rec[j] = (bk[j] << 14) | atomicAdd(&sh.u.part.tcnt[bk[j]], 1u);
-            } else if (p0 < n) {
-                uint32_t key[kLdsGroup];
-                lds_group_windows<BITS>(sh.text, g, key);
+                    for (int j = 0; j < (int)kLdsGroup; ++j) {
+                        slot[j] = atomicAdd(&sh.u.part.tcnt[tag[j]], 1u);
+                        tag[j] <<= kLdsPosBits;
+                        if (BITS == 2) tag[j] |= j ? (key[j ? j - 1 : 0] >> 30) << kLdsCodeShift : before;
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < (int)kLdsGroup; ++j) {
-                    rec[j] = 0xFFFFFFFFu;
-                    if (p0 + (uint32_t)j < n) {
-                        const uint32_t bk = sh.u.part.lut[key[j] >> kLdsFineShift];
-                        rec[j] = (bk << 14) | atomicAdd(&sh.u.part.tcnt[bk], 1u);
+                    for (int j = 0; j < (int)kLdsGroup; ++j) {
+                        tag[j] = 0xFFFFFFFFu;
+                        slot[j] = 0;
+                        if (p0 + (uint32_t)j < n) {
+                            const uint32_t bk = sh.u.part.lut[key[j] >> kLdsFineShift];
+                            slot[j] = atomicAdd(&sh.u.part.tcnt[bk], 1u);
+                            tag[j] = bk << kLdsPosBits;
+                            if (BITS == 2) tag[j] |= j ? (key[j ? j - 1 : 0] >> 30) << kLdsCodeShift : before;
+                        }
                     }
                 }
             }
@@ -536,16 +549,14 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
             if (p0 + kLdsGroup <= n) {
                 uint32_t at[kLdsGroup];
 #pragma unroll
-                for (int j = 0; j < (int)kLdsGroup; ++j) at[j] = sh.u.part.tstart[rec[j] >> 14] + (rec[j] & 16383u);
+                for (int j = 0; j < (int)kLdsGroup; ++j) at[j] = sh.u.part.tstart[(tag[j] >> kLdsPosBits) & (kLdsBuckets - 1u)] + slot[j];
 #pragma unroll
-                for (int j = 0; j < (int)kLdsGroup; ++j) sh.u.part.stage[at[j]] = (p0 + (uint32_t)j) | ((rec[j] >> 14) << kLdsPosBits);
+                for (int j = 0; j < (int)kLdsGroup; ++j) sh.u.part.stage[at[j]] = tag[j] | (p0 + (uint32_t)j);
             } else if (p0 < n) {
 #pragma unroll
                 for (int j = 0; j < (int)kLdsGroup; ++j)
-                    if (rec[j] != 0xFFFFFFFFu) {
-                        const uint32_t bk = rec[j] >> 14;
-                        sh.u.part.stage[sh.u.part.tstart[bk] + (rec[j] & 16383u)] = (p0 + (uint32_t)j) | (bk << kLdsPosBits);
-                    }
+                    if (tag[j] != 0xFFFFFFFFu)
+                        sh.u.part.stage[sh.u.part.tstart[(tag[j] >> kLdsPosBits) & (kLdsBuckets - 1u)] + slot[j]] = tag[j] | (p0 + (uint32_t)j);
             }
             __syncthreads();
             const uint32_t tcount = min(kLdsTile, n - tile * kLdsTile);
@@ -554,17 +565,16 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
 #pragma unroll
                 for (int i = 0; i < (int)kLdsGroup; ++i) v[i] = sh.u.part.stage[(uint32_t)i * kLdsThreads + (uint32_t)tid];
 #pragma unroll
-                for (int i = 0; i < (int)kLdsGroup; ++i) dl[i] = sh.u.part.delta[v[i] >> kLdsPosBits];
+                for (int i = 0; i < (int)kLdsGroup; ++i) dl[i] = sh.u.part.delta[(v[i] >> kLdsPosBits) & (kLdsBuckets - 1u)];
 #pragma unroll
-                for (int i = 0; i < (int)kLdsGroup; ++i)
-                    store_global(sa + (dl[i] + (uint32_t)i * kLdsThreads + (uint32_t)tid), v[i] & ((1u << kLdsPosBits) - 1u));
+                for (int i = 0; i < (int)kLdsGroup; ++i) store_global(sa + (dl[i] + (uint32_t)i * kLdsThreads + (uint32_t)tid), v[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < (int)kLdsGroup; ++i) {
                     const uint32_t j = (uint32_t)i * kLdsThreads + (uint32_t)tid;
                     if (j < tcount) {
                         const uint32_t v = sh.u.part.stage[j];
-                        store_global(sa + (sh.u.part.delta[v >> kLdsPosBits] + j), v & ((1u << kLdsPosBits) - 1u));
+                        store_global(sa + (sh.u.part.delta[(v >> kLdsPosBits) & (kLdsBuckets - 1u)] + j), v);
                     }
                 }
             }
