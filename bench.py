@@ -42,6 +42,9 @@ WORKLOADS = {
     "random-1g-64k": ("random255", 64 * 1024, 1 * GIB, 2, "1 GiB uniform bytes over 0x00-0xFE, 64 KiB blocks (BASELINE configs[1])"),
     "period7-1g-256k": ("period7", 256 * 1024, 1 * GIB, 4, "1 GiB period-7 text, 256 KiB blocks (BASELINE configs[3])"),
     "mixed-4g-1m": ("mixed", 1024 * 1024, 4 * GIB, 5, "4 GiB-per-GPU slice of the mixed corpus, 1 MiB blocks (BASELINE configs[4], sharded)"),
+    # sub-cases of configs[3]: period 1 and a random unit of period 64 (same seed family as period-7)
+    "period1-1g-256k": ("period1", 256 * 1024, 1 * GIB, 4, "1 GiB of one repeated byte, 256 KiB blocks (sub-case of BASELINE configs[3])"),
+    "period64-1g-256k": ("period64", 256 * 1024, 1 * GIB, 4, "1 GiB of a random 64-byte unit repeated, 256 KiB blocks (sub-case of BASELINE configs[3])"),
     # not a BASELINE config: the shape of a single file (few large blocks), which takes the device-wide
     # forward path and the tiled inverse table build instead of the one-workgroup-per-block kernels
     "acgt-16m-1m": ("acgt", 1024 * 1024, 16 * MIB, 3, "16 MiB ACGT text, 1 MiB blocks: few large blocks (one file)"),
@@ -106,6 +109,7 @@ def main() -> None:
     ap.add_argument("--block-size", type=int, default=0, help="override the block size (exploration only)")
     ap.add_argument("--kind", default="", help="override the generator kind (exploration only)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--other-cpu-sample-mib", type=int, default=16, help="CPU reference sample of each of the other workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run through the command-line tools")
     ap.add_argument("--no-other-workloads", action="store_true",
@@ -383,9 +387,15 @@ def main() -> None:
                      "roundtrip_verified": r2["ok"],
                      "later_rounds_per_block": r2["phase_share"]["later_rounds_per_block"]}
             entry.update(roofline_entries(name, r2["nbytes"], r2["nblocks"], r2["fwd_ms"], r2["inv_ms"]))
-            if k2.startswith("file:") and rank == 0 and world == 1 and not args.no_cpu_baseline:
-                # the reference's own CPU-runnable case: the CPU reference is timed on the whole file
-                entry["cpu_baseline"] = cpu_reference(k2, bs2, r2["nbytes"], r2["seed"], r2["d_fwd"])
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # the CPU reference beside every workload, its forward bytes compared with the GPU's: the
+                # reference's own CPU-runnable case (the file) in full, the others on a prefix of whole blocks
+                sample2 = r2["nbytes"]
+                if not k2.startswith("file:"):
+                    sample2 = min(sample2, args.other_cpu_sample_mib * MIB)
+                    if sample2 > bs2:
+                        sample2 -= sample2 % bs2
+                entry["cpu_baseline"] = cpu_reference(k2, bs2, sample2, r2["seed"], r2["d_fwd"])
             others.append(entry)
             all_ok = all_ok and r2["ok"]
             del r2

@@ -27,7 +27,7 @@ PASSES = 3  # warm-up 1 + steps 2 in tools/profile_round.sh
 def algorithmic_bytes(kernel: str, n: int, nb: int):
     """Bytes of the kernel's own inputs and outputs for a batch of n text bytes in nb blocks."""
     rows = n + nb
-    if "bwt_forward_kernel" in kernel or "bwt_forward_small" in kernel:
+    if "bwt_forward_kernel" in kernel or "bwt_forward_small" in kernel or "bwt_forward_lds_kernel" in kernel:
         return n + rows  # text in, transformed blocks out
     if "inverse_packed_kernel" in kernel:
         return rows + n  # transformed bytes in, text out: everything between stays in LDS
@@ -62,6 +62,10 @@ def main():
         shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(prof, "%s_kernel_stats_%s.csv" % (tag, wl)))
         shutil.copy(os.path.join(src, "pmc.json"), os.path.join(prof, "%s_pmc_%s.json" % (tag, wl)))
         pmc = json.load(open(os.path.join(src, "pmc.json")))
+        sq = {}
+        if os.path.exists(os.path.join(src, "sq.json")):
+            shutil.copy(os.path.join(src, "sq.json"), os.path.join(prof, "%s_sq_%s.json" % (tag, wl)))
+            sq = json.load(open(os.path.join(src, "sq.json")))
         kind, bs, n, _, _ = bench.WORKLOADS[wl]
         if kind.startswith("file:"):
             n = os.path.getsize(os.path.join(bench.CORPUS, kind[5:]))
@@ -94,14 +98,36 @@ def main():
                 "counter_GBps": round(hbm / (per_pass_ms * 1e-3) / 1e9, 1),
                 "counter_frac_of_hbm_peak": round(hbm / (per_pass_ms * 1e-3) / HBM, 4),
             })
+            q = sq.get(name)
+            if q and q.get("SQ_WAVE_CYCLES"):
+                # per launch of one pass, summed over the chip: instructions by kind, and how busy the issue
+                # slots and the LDS pipe were (a wave64 vector instruction holds its SIMD for four cycles;
+                # SQ_BUSY_CYCLES counts per shader engine, 32 of them x 8 compute units x 4 SIMDs)
+                busy = q.get("SQ_BUSY_CYCLES", 0.0)
+                rows[-1]["sq"] = {
+                    "insts_valu": q.get("SQ_INSTS_VALU"), "insts_salu": q.get("SQ_INSTS_SALU"), "insts_lds": q.get("SQ_INSTS_LDS"),
+                    "insts_vmem_rd": q.get("SQ_INSTS_VMEM_RD"), "insts_vmem_wr": q.get("SQ_INSTS_VMEM_WR"),
+                    "lds_bank_conflict_share_of_lds_active": round(q.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, q.get("SQ_LDS_IDX_ACTIVE", 0.0)), 3),
+                    "wave_cycles_waiting_share": round(q.get("SQ_WAIT_ANY", 0.0) / max(1.0, q.get("SQ_WAVE_CYCLES", 0.0)), 3),
+                    "wave_cycles_waiting_for_lds_share": round(q.get("SQ_WAIT_INST_LDS", 0.0) / max(1.0, q.get("SQ_WAVE_CYCLES", 0.0)), 3),
+                    "valu_busy_share_of_simd_cycles": None if not busy else round(q.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (busy * 32.0), 3),
+                }
             if "forward" in short or "grid_" in short:
                 tot["forward"] += hbm
             elif "inverse" in short:
                 tot["inverse"] += hbm
+        # A launch that finds its blocks finished by an earlier kernel (the general forward kernels behind the
+        # text-in-LDS one, the inverse table kernels behind the in-LDS inverse) returns at once: its counters show
+        # next to no traffic, and pricing it at the batch's bytes would print fractions above 1.  No figure then.
+        for k in rows:
+            moved = (k["counter_fetch_GB"] + k["counter_write_GB"]) * 1e9
+            if k["algorithmic_bytes"] is not None and moved < 0.05 * k["algorithmic_bytes"]:
+                k["algorithmic_bytes"] = k["algorithmic_GBps"] = k["frac_of_hbm_peak"] = None
+                k["note"] = "finds every block finished by an earlier kernel and returns"
         rows.sort(key=lambda k: -k["avg_launch_ms"] * k["launches_per_pass"])
         # the two forward instantiations share one pass's bytes: price them on the one that did the work
-        fw = [k for k in rows if k["name"].startswith("bwt_forward_kernel")]
-        for k in fw[1:]:
+        fw = [k for k in rows if k["name"].startswith("bwt_forward_kernel") and k["algorithmic_bytes"] is not None]
+        for k in fw[1:] if fw else []:
             if k["avg_launch_ms"] * k["launches_per_pass"] < 0.05 * fw[0]["avg_launch_ms"] * fw[0]["launches_per_pass"]:
                 k["algorithmic_bytes"] = k["algorithmic_GBps"] = k["frac_of_hbm_peak"] = None
         kernels[wl] = {"source": "profiles/%s_kernel_stats_%s.csv + profiles/%s_pmc_%s.json" % (tag, wl, tag, wl),
