@@ -2312,9 +2312,11 @@ struct PeriodWords {  // the two LDS words the search needs (FwdShared has them 
     uint32_t period_cand, period_bad;
 };
 
+// max_period: periods above it are not looked for (a caller that only wants the cheap cases -- the
+// search for the window's next occurrence then reads that much of the block and no more).
 template <int NT, typename Shared>
 __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__ s, uint32_t len, const uint8_t* g_lo,
-                                                      const uint8_t* g_hi, Shared& sh) {
+                                                      const uint8_t* g_hi, Shared& sh, uint32_t max_period = 0xFFFFFFFFu) {
     const int tid = threadIdx.x, lane = lane_id();
     if (len < 16384u) return 0;  // workgroup-uniform (the windows below reach 4 KiB + len / 3 into the block)
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3u);
@@ -2333,7 +2335,8 @@ __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__
     __syncthreads();
     const uint8_t* pat = s + i0;
     const uint32_t pat0 = (uint32_t)pat[0] | ((uint32_t)pat[1] << 8) | ((uint32_t)pat[2] << 16) | ((uint32_t)pat[3] << 24);
-    const uint32_t limit = len / 3u;  // candidates 1 .. limit (window at i0 + candidate: i0 + len / 3 + 16 <= len)
+    const uint32_t limit = min(len / 3u, max_period);  // candidates 1 .. limit (window at i0 + candidate: i0 + len / 3 + 16 <= len)
+    const uint32_t pat1 = (uint32_t)pat[4] | ((uint32_t)pat[5] << 8) | ((uint32_t)pat[6] << 16) | ((uint32_t)pat[7] << 24);
     constexpr int U = 4;  // dword pairs whose loads are issued together
     uint32_t from = 0;  // candidates up to here have been tried
 #pragma unroll 1
@@ -2349,21 +2352,24 @@ __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__
         for (uint32_t q0 = q_first + (uint32_t)tid; q0 < q_end; q0 += U * NT) {
             const uint32_t cand = *(volatile uint32_t*)&sh.period_cand;
             if (cand != 0xFFFFFFFFu && cand + i0 + mis < 4u * (q0 - (uint32_t)tid)) break;  // every place from here on lies behind one already found
-            uint32_t w0[U], w1[U];
+            uint32_t w0[U], w1[U], w2[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t q = q0 + (uint32_t)(u * NT);
                 w0[u] = load_dword_guarded(ab + 4u * (uint64_t)q, g_lo, g_hi);
                 w1[u] = load_dword_guarded(ab + 4u * (uint64_t)q + 4u, g_lo, g_hi);
+                w2[u] = load_dword_guarded(ab + 4u * (uint64_t)q + 8u, g_lo, g_hi);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t q = q0 + (uint32_t)(u * NT);
 #pragma unroll
                 for (uint32_t o = 0; o < 4u; ++o) {
+                    // the window's first eight bytes (four would match every 256th place of a four-letter text)
                     const uint32_t v = o == 0 ? w0[u] : __builtin_amdgcn_alignbyte(w1[u], w0[u], o);
+                    const uint32_t v1 = o == 0 ? w1[u] : __builtin_amdgcn_alignbyte(w2[u], w1[u], o);
                     const uint32_t at = 4u * q + o;  // byte offset from ab
-                    if (v == pat0 && at > i0 + from + mis && at - mis - i0 <= limit) {
+                    if (v == pat0 && v1 == pat1 && at > i0 + from + mis && at - mis - i0 <= limit) {
                         const uint32_t i = at - mis;  // block position of the occurrence
                         // the window, and three more 1 KiB apart (a locally repetitive stretch -- a ruled
                         // line in a text -- repeats the one window many times, but not all four)

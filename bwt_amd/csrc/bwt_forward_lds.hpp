@@ -69,6 +69,7 @@ constexpr int kLdsPosBits = 19;                  // positions 0 .. 262144
 constexpr uint32_t kLdsPosMask = (1u << 19) - 1u;
 constexpr int kLdsCodeShift = 29;                // a scratch word: position | bucket << 19 | (two-bit text) code of the symbol before << 29
 constexpr int kLdsDepth = 8;                     // windows two suffixes are compared over before the block is given up
+constexpr uint32_t kLdsMaxPeriod = 4096;         // whole-block periods up to here are looked for before anything else
 constexpr int kLdsClockSlot = 32;                // phase clocks: u64 words from queue + 2 * kLdsClockSlot
 
 struct LdsWaveArea {
@@ -99,6 +100,7 @@ struct LdsShared {
     uint64_t ball[4];
     uint32_t cb[4];                // code -> byte
     uint32_t blk, bad, next;
+    uint32_t period_cand, period_bad;  // detect_block_period's words
 };
 static_assert(sizeof(LdsShared) <= 160u * 1024u, "one workgroup's LDS");
 
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
         const uint32_t len = rem < a.block_size ? (uint32_t)rem : a.block_size;
         const uint8_t* __restrict__ s = a.in + off;
         uint8_t* __restrict__ out = a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u);
-        bool done = false;
+        bool done = false, tried = false;
         if (len >= kLdsMinLen && len <= kLdsMaxLen2) {  // workgroup-uniform
             // ---- the alphabet, from 16 bytes per lane spread over the block
             {
@@ -698,7 +700,9 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
                 if (i < w) below += c;
             }
             const bool delim_seen = ((sh.ball[a.delim >> 6] >> (a.delim & 63u)) & 1ull) != 0ull;
-            if (!delim_seen && sigma <= 4u) {
+            if (!delim_seen && sigma == 1u) {
+                tried = true;  // one byte value throughout (as far as the sample shows): a run, the other launch's business
+            } else if (!delim_seen && sigma <= 4u) {
                 if (tid < 256) {
                     const uint32_t code = below + (uint32_t)__popcll(bal & lanemask_lt());
                     sh.code[tid] = present ? (uint8_t)code : (uint8_t)0x80;
@@ -710,14 +714,26 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) dr += (i < sigma && ((cbytes >> (8u * i)) & 255u) < a.delim) ? 1u : 0u;
                 pc.lap(kLdsClockSlot + 0);
+                tried = true;
                 done = lds_forward_block<2>(s, len, a.delim, out, sa, sh, sigma, dr, cbytes, pc);
             } else if (!delim_seen && len <= kLdsMaxLen8) {
                 pc.lap(kLdsClockSlot + 0);
+                tried = true;
                 done = lds_forward_block<8>(s, len, a.delim, out, sa, sh, 256u, a.delim, 0u, pc);
             }
         }
-        if (tid == 0) {
-            if (!done) a.normal[atomicAdd(&a.queue[5], 1u)] = b;
+        // Where a block that is not finished goes.  One that was tried and given up has overfull buckets or
+        // long repeats -- runs, periodic or repeated text: the launch with the machinery for such blocks
+        // (a.deferred), which also looks for whole-block periods itself.  One that never qualified (too many
+        // symbols for its length) goes to the common-case launch (a.normal) -- unless it repeats a short unit
+        // throughout, which that launch would only notice after a wasted round: looked for here (reads up to
+        // kLdsMaxPeriod + 1 KiB of the block; a full comparison only if the unit is found again).
+        bool heavy = tried;
+        if (!done && !tried && len >= kPeriodicMinBlock)
+            heavy = detect_block_period<kLdsThreads>(s, len, a.in, a.in + a.total_len, sh, kLdsMaxPeriod) != 0u;
+        if (tid == 0 && !done) {
+            if (heavy) a.deferred[atomicAdd(&a.queue[2], 1u)] = b;
+            else a.normal[atomicAdd(&a.queue[5], 1u)] = b;
         }
         pc.count(kLdsClockSlot + (done ? 6 : 7), 1);
     }
