@@ -155,6 +155,20 @@ struct FwdGeom {
 // batch kernel 0.2 ms plus 8.5 us per KiB of ONE block (text: 25 us) as long as every block has
 // a workgroup of its own.  The former wins for up to a few dozen blocks unless they are short.
 constexpr size_t kClassifyMinBlock = (size_t)512 << 10;  // batch kernels: blocks at least this long are checked for whole-block periods before they are sorted
+// BWTGPU_CLASSIFY_MIN_BLOCK=<bytes> moves that threshold, and BWTGPU_NARROW=1 keeps batches of few blocks on the
+// 256-thread kernels: how the tests send small batches through the classifying launch and both of its lists.
+size_t classify_min_block() {
+    const char* e = std::getenv("BWTGPU_CLASSIFY_MIN_BLOCK");
+    if (e && *e) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 32768) return (size_t)v;
+    }
+    return kClassifyMinBlock;
+}
+bool force_narrow() {
+    const char* e = std::getenv("BWTGPU_NARROW");
+    return e && !strcmp(e, "1");
+}
 constexpr size_t kGridMaxBlocks = 32;
 constexpr size_t kGridMinBlock = 20000;      // bytes in the (longest) block
 constexpr size_t kGridMaxRows = (size_t)1 << 31;
@@ -235,7 +249,7 @@ FwdGeom fwd_geom(const Device& d, size_t total_len, size_t block_size) {
     g.grid = (uint32_t)std::max<size_t>(1, std::min(g.nblocks, max_wgs));
     // With fewer blocks than compute units most of the chip idles and a block's latency is the
     // whole cost: give every block a 1024-thread workgroup instead.
-    g.wide = g.nblocks <= (size_t)d.cus && longest >= kWideMinBlock;
+    g.wide = g.nblocks <= (size_t)d.cus && longest >= kWideMinBlock && !force_narrow();
     g.bytes = kHeaderBytes + g.stride * g.grid + 2 * round_up(g.nblocks * 4, 256);  // + the lists of blocks put off / left to the first launch
     // The device-wide path serves the batch itself or, when a caller sizes its workspace for a
     // full slab and then submits a shorter one, any prefix of it.
@@ -468,6 +482,7 @@ int ensure_device(int device) {
     void* sp = nullptr;
     d->static_ws_error = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
     d->static_ws = d->static_ws_error == hipSuccess ? (uint8_t*)sp : nullptr;
+    if (d->static_ws_error != hipSuccess) (void)hipGetLastError();  // the failure stays with bwtgpu_forward_batch_static, which reports it
     if (hipHostMalloc((void**)&d->inv_left, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess &&
         hipHostGetDevicePointer((void**)&d->inv_left_dev, d->inv_left, 0) == hipSuccess) {
         *d->inv_left = 0xFFFFFFFFu;
@@ -668,7 +683,7 @@ int forward_blocks(const Device& d, const FwdGeom& g, const uint8_t* d_in, size_
             return BWTGPU_OK;
         }
         // long blocks: whole-block periods are looked for up front (bwt_forward_classify_kernel)
-        const bool classify = block_size >= kClassifyMinBlock;
+        const bool classify = block_size >= classify_min_block() && !lds_first;
         if (classify) hipLaunchKernelGGL(bwt_forward_classify_kernel<256>, dim3((uint32_t)std::min<size_t>(g.nblocks, (size_t)d.cus * 8)), dim3(256), 0, s, a);
         hipLaunchKernelGGL((bwt_forward_kernel<kFwdThreads, false>), dim3(g.grid), dim3(kFwdThreads), 0, s, a, classify || lds_first ? 2 : 0);
         // debugging aid: BWTGPU_PHASES=second makes the phase clocks in the header cover the second launch only
@@ -755,8 +770,19 @@ extern "C" {
 const char* bwtgpu_last_error(void) { return g_err; }
 
 int bwtgpu_init(int n_devices) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    return init_locked(n_devices);
+    int count;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        count = init_locked(n_devices);
+    }
+    // Bind every device now -- stream, pinned word, occupancy queries, the address of the static scratch --
+    // so that no later entry point has anything left to create (bwtgpu_forward_batch_static promises to
+    // allocate nothing, also as the first call after this one).
+    for (int i = 0; i < count; ++i) {
+        const int rc = ensure_device(i);
+        if (rc) return rc;
+    }
+    return count;
 }
 
 void bwtgpu_shutdown(void) {
@@ -764,6 +790,8 @@ void bwtgpu_shutdown(void) {
     for (size_t i = 0; i < g_dev.size(); ++i) {
         Device* d = g_dev[i];
         if (hipSetDevice((int)i) != hipSuccess) continue;
+        // a batch still queued on a caller's stream writes the pinned word below at its end
+        if (d->ready) (void)hipDeviceSynchronize();
         if (d->d_in) (void)hipFree(d->d_in);
         if (d->d_out) (void)hipFree(d->d_out);
         if (d->d_ws) (void)hipFree(d->d_ws);
@@ -831,8 +859,14 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
 
 int bwtgpu_forward_batch_static(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
                                 uint8_t delimiter, uint8_t* d_out, uint32_t* d_status, void* stream) {
-    int rc = check_device(device);
-    if (rc) return rc;
+    int rc;
+    {   // never binds a device itself (that creates a stream and pinned memory): bwtgpu_init has done it
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (device < 0 || device >= (int)g_dev.size())
+            return fail(BWTGPU_ERR_NO_DEVICE, "device %d is not bound (%d bound): call bwtgpu_init first", device, (int)g_dev.size());
+        if (!g_dev[device]->ready)
+            return fail(BWTGPU_ERR_NO_DEVICE, "device %d is not bound: call bwtgpu_init first", device);
+    }
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
     block_size = forward_block_size(total_len, block_size);
     if (block_size > kBlockKernelMaxBlock)

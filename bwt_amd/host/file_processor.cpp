@@ -96,6 +96,10 @@ bool FileProcessor::has_more_data() const {
 
 size_t FileProcessor::read_bytes(char* dst, size_t max_bytes) {
     std::lock_guard<std::mutex> lock(mutex_);
+    return read_bytes_locked(dst, max_bytes);
+}
+
+size_t FileProcessor::read_bytes_locked(char* dst, size_t max_bytes) {
     if (!good_ || max_bytes == 0) return 0;
     size_t got;
     const off_t pos = regular_ && max_bytes >= kParallelMin ? ::ftello(in_) : (off_t)-1;
@@ -120,8 +124,11 @@ size_t FileProcessor::read_bytes(char* dst, size_t max_bytes) {
 }
 
 std::string FileProcessor::read_chunk() {
+    // the lock covers the shared staging buffer as well as the stream (reference src/file_processor.cpp:38-53
+    // holds its lock for the whole call)
+    std::lock_guard<std::mutex> lock(mutex_);
     if (scratch_.size() < block_size_) scratch_.resize(block_size_);
-    const size_t got = read_bytes(scratch_.data(), block_size_);
+    const size_t got = read_bytes_locked(scratch_.data(), block_size_);
     return std::string(scratch_.data(), got);
 }
 

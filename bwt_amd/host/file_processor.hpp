@@ -45,6 +45,7 @@ public:
     bool input_is_regular() const;
 
 private:
+    size_t read_bytes_locked(char* dst, size_t max_bytes);  // mutex_ held by the caller
     std::FILE* in_ = nullptr;
     std::FILE* out_ = nullptr;
     size_t block_size_;

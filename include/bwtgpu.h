@@ -60,10 +60,15 @@ extern "C" {
 
 /* ---- lifecycle --------------------------------------------------------- */
 
-/* Binds the library to the first `n_devices` visible HIP devices (0 = all).
- * Returns the number of devices in use (> 0) or a negative error.  Idempotent. */
+/* Binds the library to the first `n_devices` visible HIP devices (0 = all): per device a staging stream,
+ * a pinned status word, launch geometry and the address of the static scratch are set up here, so that
+ * no later call has anything left to create on a bound device.  Returns the number of devices in use
+ * (> 0) or a negative error.  Idempotent.  Every other entry point binds the devices itself on first
+ * use EXCEPT bwtgpu_forward_batch_static, which requires this call to have been made. */
 int bwtgpu_init(int n_devices);
-/* Releases cached device buffers and streams. */
+/* Waits for the work queued on every bound device, then releases cached device buffers and streams.
+ * Call it only after every stream that was handed to a "_device" entry point has been synchronised or
+ * destroyed: work still queued may write library-owned memory that this call frees. */
 void bwtgpu_shutdown(void);
 /* Number of devices bound by bwtgpu_init (0 before init / without a GPU). */
 int bwtgpu_device_count(void);
@@ -95,7 +100,9 @@ int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t
  * capture, tight serving loops, harnesses that forbid hipMalloc.  Same transform and same bytes as
  * bwtgpu_forward_batch_device, but the scratch is a fixed array of BWTGPU_STATIC_SCRATCH_BYTES that
  * lives in the library's code object on every GPU (each GPU holds its copy until the process ends),
- * and the call itself allocates nothing, on host or device.  Limits: block_size (after clamping to
+ * and the call itself allocates nothing, on host or device -- bwtgpu_init must have bound the device
+ * before (BWTGPU_ERR_NO_DEVICE otherwise: this call never binds one, which would create a stream and
+ * pinned memory).  Limits: block_size (after clamping to
  * the batch) at most 2 MiB - 1 (BWTGPU_ERR_BLOCK_TOO_LARGE), and the batch's block lists (8 bytes per
  * block) plus one block's slice (20 bytes per block byte) must fit the array (BWTGPU_ERR_WORKSPACE).
  * Throughput is lower than with a caller-sized workspace: only as many blocks are in flight as

@@ -548,6 +548,53 @@ def test_whole_block_periods(orc):
             assert api.inverse_batch(got, bs, delim) == raw
 
 
+def test_classifying_launch_and_both_lists(orc, forward_path):
+    """The launch that looks for whole-block periods before anything is sorted (the library uses it for
+    batches of blocks of at least 512 KiB on the 256-thread kernels, which no small test batch reaches):
+    the threshold lowered and the 1024-thread variant ruled out, a batch of periodic and ordinary blocks
+    with a ragged tail goes through it and through both of the lists it fills; and the mixed corpus'
+    vectors the same way."""
+    if forward_path != "block":
+        pytest.skip("one route: the general batch kernels behind the classifying launch")
+    rng = np.random.default_rng(99)
+    old = {k: os.environ.get(k) for k in ("BWTGPU_CLASSIFY_MIN_BLOCK", "BWTGPU_NARROW")}
+    os.environ["BWTGPU_CLASSIFY_MIN_BLOCK"] = "32768"
+    os.environ["BWTGPU_NARROW"] = "1"
+    try:
+        bs = 40000
+        unit7 = np.frombuffer(b"abcdefg", np.uint8)
+        unit300 = rng.integers(1, 250, size=300, dtype=np.uint8)
+        parts = [np.tile(unit7, bs // 7 + 1)[:bs], rng.integers(0, 250, size=bs, dtype=np.uint8),
+                 np.tile(unit300, bs // 300 + 1)[:bs], np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=bs)],
+                 np.full(bs, 65, np.uint8), rng.integers(97, 123, size=bs, dtype=np.uint8),
+                 np.tile(unit7, 4000)[:17001]]
+        data = np.concatenate(parts).astype(np.uint8).tobytes()
+        want = orc.forward_buffer(data, bs, 8)
+        got = api.forward_batch(data, bs, want[0])
+        assert got == want[1:]
+        assert api.inverse_batch(got, bs, want[0]) == data
+        text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+        row = load_mixed()[0]
+        data = synth.generate("mixed", row["seed"], row["offset"], row["length"], text=text).tobytes()
+        got = api.forward_batch(data, row["block_size"], row["delimiter"])
+        for i, sha in enumerate(row["block_forward_sha256"]):
+            blk = got[i * (row["block_size"] + 1):(i + 1) * (row["block_size"] + 1)]
+            assert hashlib.sha256(blk).hexdigest() == sha, i
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def load_mixed():
+    import json
+
+    with open(os.path.join(GOLDEN, "mixed.json")) as f:
+        return json.load(f)
+
+
 def test_blocks_above_two_mib(orc, forward_path):
     """Blocks too long for the one-workgroup kernels: device-wide forward path, 64-bit inverse
     table words, coarser segments.  Against the oracle at 3 and 5 MiB, by round trip at 48 MiB."""

@@ -95,3 +95,47 @@ def test_static_scratch_limits_are_reported():
     torch.cuda.synchronize()
     assert int(d_status.item()) == 0
     torch.cuda.synchronize()
+
+
+_FIRST_CALL = r"""
+import ctypes, sys
+import numpy as np
+import torch
+torch.cuda.is_available()
+sys.path.insert(0, {root!r})
+import oracle
+from bwt_amd import api, synth
+L = api.lib()
+dev = torch.device("cuda", 0)
+data = synth.generate("acgt", synth.base_seed(3), 0, 5 * 65536 + 777)
+n, bs, delim = int(data.size), 65536, 0
+nb = L.bwtgpu_num_blocks(n, bs)
+d_in = torch.from_numpy(data.copy()).to(dev)
+d_out = torch.zeros(n + nb, dtype=torch.uint8, device=dev)
+d_status = torch.full((1,), 0x7FFFFFFF, dtype=torch.int32, device=dev)
+vp = ctypes.c_void_p
+stream = torch.cuda.current_stream().cuda_stream
+# before bwtgpu_init the entry point refuses: it never binds a device by itself
+rc = L.bwtgpu_forward_batch_static(0, vp(d_in.data_ptr()), n, bs, delim, vp(d_out.data_ptr()), vp(d_status.data_ptr()), stream)
+assert rc == api.ERR_NO_DEVICE, rc
+assert L.bwtgpu_init(1) >= 1
+# ... and right after it, as the library's first call that touches the device, it works
+rc = L.bwtgpu_forward_batch_static(0, vp(d_in.data_ptr()), n, bs, delim, vp(d_out.data_ptr()), vp(d_status.data_ptr()), stream)
+assert rc == 0, api.last_error()
+torch.cuda.synchronize()
+assert int(d_status.item()) == 0
+want = oracle.oracle().forward_buffer(data.tobytes(), bs, 4)
+assert want[0] == delim and d_out.cpu().numpy().tobytes() == want[1:]
+print("first-call ok")
+"""
+
+
+def test_static_entry_point_is_usable_as_the_first_call_after_init():
+    """A fresh process: the static entry point refuses before bwtgpu_init (it binds no device itself, which
+    would create a stream and pinned memory), and works as the very first device call after it."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _FIRST_CALL.format(root=root)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "first-call ok" in out.stdout, out.stdout + out.stderr
