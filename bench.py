@@ -240,6 +240,11 @@ def main() -> None:
         for k, v in zip(["sample", "pack", "count", "assign", "partition", "sort"], lds[:6]):
             phase_share["lds_" + k] = round(float(v) / lds_tot, 4)
         phase_share["lds_blocks_done_given_up"] = [int(lds[6]), int(lds[7])]
+        t16 = d_ws_i[256:256 + 64].cpu().numpy().view("uint64").astype(float)  # the in-LDS table inverse's clocks
+        if t16[6]:
+            t16_tot = max(1.0, float(t16[:6].sum() + t16[7]))
+            phase_share["inverse_t16"] = dict({k: round(float(v) / t16_tot, 4) for k, v in zip(["count", "scan", "table", "walk1", "order", "walk2"], t16[:6])},
+                                              other=round(float(t16[7]) / t16_tot, 4), blocks=int(t16[6]))
         inv_clk = d_ws_i[64:64 + 128].cpu().numpy().view("uint64")  # debug builds of the library only
         if inv_clk.any():
             phase_share["inverse_stitch_clocks"] = [int(v) for v in inv_clk]

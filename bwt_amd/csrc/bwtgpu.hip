@@ -18,6 +18,7 @@
 #include "bwt_inverse.hpp"
 #include "bwt_inverse_small.hpp"
 #include "bwt_inverse_packed.hpp"
+#include "bwt_inverse_t16.hpp"
 #include "bwtgpu.h"
 
 namespace {
@@ -986,6 +987,9 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
                                dim3((uint32_t)((g.nblocks + kPackClassifyThreads / kWave - 1) / (kPackClassifyThreads / kWave))),
                                dim3(kPackClassifyThreads), 0, s, a);
             hipLaunchKernelGGL(bwt_inverse_packed_kernel, dim3(g.pack_wgs), dim3(kPackThreads), 0, s, a);
+            // blocks of at most 64 KiB over any alphabet: their whole LF table fits LDS as 16-bit entries
+            if (block_size + 1 <= (size_t)kT16MaxRows)
+                hipLaunchKernelGGL(bwt_inverse_t16_kernel, dim3(g.pack_wgs), dim3(kT16Threads), 0, s, a);
             HIP_TRY(hipGetLastError());
         }
     }

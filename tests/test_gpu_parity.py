@@ -284,6 +284,52 @@ def test_text_in_lds_forward(orc, forward_path):
         assert api.forward_batch(data, bs, want[0]) == want[1:], (bs, total)
 
 
+def test_lds_table_inverse(orc):
+    """Blocks of 48 K to 64 K + 1 rows over any alphabet (their LF table fits LDS as 16-bit entries):
+    lengths around the limits, alphabets from 2 to 255 values, skewed ones (symbols with fewer than
+    64 rows: the first-column lookup steps over several), text, the delimiter below / between / above,
+    the delimiter row first / last, hand-made blocks with several LF cycles, none or two delimiters,
+    and more blocks than compute units with a ragged tail."""
+    rng = np.random.default_rng(1616)
+    text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+    cases = []
+    for n in [49151, 49152, 49153, 50000, 65535, 65536]:
+        cases.append((rng.integers(0, 255, size=n, dtype=np.uint8).tobytes(), 255))
+        cases.append((rng.integers(1, 256, size=n, dtype=np.uint8).tobytes(), 0))
+        cases.append(((rng.integers(0, 100, size=n, dtype=np.uint8) * 2).astype(np.uint8).tobytes(), 101))
+        cases.append((rng.integers(0, 7, size=n, dtype=np.uint8).tobytes(), 200))
+        sk = rng.integers(0, 250, size=n, dtype=np.uint8)
+        sk[rng.random(n) < 0.95] = 65  # 249 rare symbols, a few dozen rows each
+        cases.append((sk.tobytes(), 255))
+        cases.append((text[1000:1000 + n], 0))
+    cases += [(b"C" * 50000, ord("A")), (b"C" * 50000, ord("T")), (b"AC" * 26000, ord("B")),
+              ((b"abcdefg" * 9000)[:60000], 0), (bytes(range(1, 256)) * 250, 0)]
+    for data, delim in cases:
+        fwd = orc.forward(data, delim)
+        assert api.bwt_inverse(fwd, delim) == data, (len(data), delim)
+    prng = random.Random(16)
+    for n, sigma in [(50000, 200), (60000, 5), (65537, 254), (65537, 30)]:
+        blk = bytearray(prng.randrange(1, 1 + sigma) for _ in range(n))
+        blk[prng.randrange(n)] = 0
+        assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0), (n, sigma)
+    blk = bytearray(rng.integers(1, 200, size=60000, dtype=np.uint8).tobytes())
+    with pytest.raises(api.BwtGpuError):
+        api.bwt_inverse(bytes(blk), 0)
+    blk[5] = 0
+    blk[47000] = 0
+    assert api.bwt_inverse(bytes(blk), 0) == orc.inverse(bytes(blk), 0)
+    # more blocks than compute units, every 5th one DNA (the two-bit kernel's), a ragged tail
+    bs = 65536
+    for nblocks, tail in [(300, 50001), (270, 20000)]:
+        total = (nblocks - 1) * bs + tail
+        data = rng.integers(0, 251, size=total, dtype=np.uint8)
+        for b in range(3, nblocks - 1, 5):
+            data[b * bs:(b + 1) * bs] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=bs)]
+        data = data.tobytes()
+        want = orc.forward_buffer(data, bs, 8)
+        assert api.inverse_batch(want[1:], bs, want[0]) == data, (nblocks, tail)
+
+
 def test_small_alphabet_many_blocks(orc):
     """More DNA blocks than compute units (the in-LDS inverse works through a list of blocks per
     workgroup), every 37th block ordinary bytes (left to the table kernels, which skip the finished

@@ -15,5 +15,5 @@ for r in csv.DictReader(open(sys.argv[1])):
 line = [l for l in open(sys.argv[2]) if l.startswith("{")][-1]
 d = json.loads(line)
 print(d["config"]["workload"], "value", round(d["value"], 2), "fwd", round(d["forward_ms"], 2), "inv", round(d["inverse_ms"], 2),
-      {k: v for k, v in d["forward_phase_share"].items() if not isinstance(v, float) or v > 0.03 or k.startswith("lds_")})
+      {k: v for k, v in d["forward_phase_share"].items() if not isinstance(v, float) or v > 0.03 or k.startswith("lds_") or k.startswith("inverse_")})
 PY
