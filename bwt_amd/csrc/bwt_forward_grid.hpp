@@ -99,10 +99,10 @@ __device__ __forceinline__ uint32_t block_exclusive_max(uint32_t v, uint32_t* s_
 // key[g] = block << (m0*sbits) | codes of the m0 symbols from g on, id[g] = g.  Codes are dense:
 // 1 + the number of smaller byte values that occur in the batch (the delimiter counted among
 // them), which keeps the byte order and leaves 0 for "past the end".
-__global__ __launch_bounds__(kGridThreads) void grid_keys0_kernel(GridArgs a, uint64_t* __restrict__ key,
-                                                                  uint32_t* __restrict__ id, uint32_t m0,
-                                                                  uint32_t sbits) {
-    __shared__ uint16_t s_code[256];
+// s_code: 256 entries of LDS.  `first` / `nthreads`: this thread's index among all that share the work, and their number.
+__device__ __forceinline__ void grid_keys0_body(const GridArgs& a, uint64_t* __restrict__ key, uint32_t* __restrict__ id,
+                                                uint32_t m0, uint32_t sbits, uint16_t* s_code, uint32_t first,
+                                                uint32_t nthreads) {
     {
         const uint32_t c = threadIdx.x;
         uint32_t below = 0;
@@ -117,8 +117,7 @@ __global__ __launch_bounds__(kGridThreads) void grid_keys0_kernel(GridArgs a, ui
     }
     __syncthreads();
     const uint32_t dcode = s_code[a.delim];
-    const uint32_t nthreads = gridDim.x * kGridThreads;
-    for (uint32_t g = blockIdx.x * kGridThreads + threadIdx.x; g < a.rows; g += nthreads) {
+    for (uint32_t g = first; g < a.rows; g += nthreads) {
         const GridPos p = grid_pos(a, g);
         const uint8_t* __restrict__ s = a.in + (uint64_t)p.b * a.block_size;
         uint64_t k = p.b;
@@ -131,14 +130,18 @@ __global__ __launch_bounds__(kGridThreads) void grid_keys0_kernel(GridArgs a, ui
         id[g] = g;
     }
 }
+__global__ __launch_bounds__(kGridThreads) void grid_keys0_kernel(GridArgs a, uint64_t* __restrict__ key,
+                                                                  uint32_t* __restrict__ id, uint32_t m0,
+                                                                  uint32_t sbits) {
+    __shared__ uint16_t s_code[256];
+    grid_keys0_body(a, key, id, m0, sbits, s_code, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
+}
 
 // ---- later keys --------------------------------------------------------------------------------
 // key[j] = rank[g] << b2 | (rank[g+h] - first row of the block + 1, or 0 past the block's end).
-__global__ __launch_bounds__(kGridThreads) void grid_keys_kernel(GridArgs a, const uint32_t* __restrict__ id,
-                                                                 uint32_t m, uint64_t h, uint32_t b2,
-                                                                 uint64_t* __restrict__ key) {
-    const uint32_t nthreads = gridDim.x * kGridThreads;
-    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+__device__ __forceinline__ void grid_keys_body(const GridArgs& a, const uint32_t* id, uint32_t m, uint64_t h, uint32_t b2,
+                                               uint64_t* key, uint32_t first, uint32_t nthreads) {
+    for (uint32_t j = first; j < m; j += nthreads) {
         const uint32_t g = id[j];
         const GridPos p = grid_pos(a, g);
         const uint32_t base = g - p.off;
@@ -147,14 +150,16 @@ __global__ __launch_bounds__(kGridThreads) void grid_keys_kernel(GridArgs a, con
         key[j] = ((uint64_t)a.rank[g] << b2) | r2;
     }
 }
+__global__ __launch_bounds__(kGridThreads) void grid_keys_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                 uint32_t m, uint64_t h, uint32_t b2,
+                                                                 uint64_t* __restrict__ key) {
+    grid_keys_body(a, id, m, h, b2, key, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
+}
 
 // ---- device-wide LSD radix pass: count, scatter -------------------------------------------------
 // Tile t = elements [t*tile, (t+1)*tile); tile_hist[t * kGridBins + bin] = its count of digit `bin`.
-__global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t* __restrict__ key, uint32_t m,
-                                                                 uint32_t tile, uint32_t shift, uint32_t mask,
-                                                                 uint32_t* __restrict__ tile_hist) {
-    __shared__ uint32_t s_h[kGridBins];
-    const uint32_t t = blockIdx.x;
+__device__ __forceinline__ void grid_hist_body(const uint64_t* key, uint32_t m, uint32_t tile, uint32_t shift, uint32_t mask,
+                                               uint32_t* tile_hist, uint32_t t, uint32_t* s_h) {
     s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
@@ -163,6 +168,12 @@ __global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t*
     __syncthreads();
     tile_hist[t * kGridBins + threadIdx.x] = s_h[threadIdx.x];
 }
+__global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t* __restrict__ key, uint32_t m,
+                                                                 uint32_t tile, uint32_t shift, uint32_t mask,
+                                                                 uint32_t* __restrict__ tile_hist) {
+    __shared__ uint32_t s_h[kGridBins];
+    grid_hist_body(key, m, tile, shift, mask, tile_hist, blockIdx.x, s_h);
+}
 
 // Stable scatter of tile t by the digit.  Where the tile's elements of digit d start = the
 // elements of smaller digits in all tiles + those of digit d in the tiles before t: thread d
@@ -170,22 +181,26 @@ __global__ __launch_bounds__(kGridThreads) void grid_hist_kernel(const uint64_t*
 // L2; a separate scan launch costs more than these loads).  Then, per chunk of kGridChunk
 // elements: ranks by wave ballot match + per-wave counters (waves and vectors in element order),
 // the chunk gathered by digit in LDS, and written out in runs of equal digit.
-__global__ __launch_bounds__(kGridThreads) void grid_scatter_kernel(const uint64_t* __restrict__ key_in,
-                                                                    const uint32_t* __restrict__ id_in,
-                                                                    uint64_t* __restrict__ key_out,
-                                                                    uint32_t* __restrict__ id_out, uint32_t m,
-                                                                    uint32_t tile, uint32_t ntiles, uint32_t shift,
-                                                                    uint32_t mask,
-                                                                    const uint32_t* __restrict__ tile_hist) {
-    __shared__ uint32_t s_cursor[kGridBins];             // where the next element of each digit goes
-    __shared__ uint32_t s_wcnt[kGridWaves][kGridBins];   // per wave: count so far, then chunk-local start
-    __shared__ uint32_t s_gbase[kGridBins];              // output position minus chunk-local position
-    __shared__ uint32_t s_wsum[kGridWaves];
-    __shared__ uint64_t s_key[kGridChunk];
-    __shared__ uint32_t s_id[kGridChunk];
+struct GridScatterShared {
+    uint32_t cursor[kGridBins];             // where the next element of each digit goes
+    uint32_t wcnt[kGridWaves][kGridBins];   // per wave: count so far, then chunk-local start
+    uint32_t gbase[kGridBins];              // output position minus chunk-local position
+    uint32_t wsum[kGridWaves];
+    uint64_t key[kGridChunk];
+    uint32_t id[kGridChunk];
+};
+__device__ __forceinline__ void grid_scatter_body(const uint64_t* key_in, const uint32_t* id_in, uint64_t* key_out,
+                                                  uint32_t* id_out, uint32_t m, uint32_t tile, uint32_t ntiles,
+                                                  uint32_t shift, uint32_t mask, const uint32_t* tile_hist, uint32_t t,
+                                                  GridScatterShared& sh) {
+    uint32_t* s_cursor = sh.cursor;
+    uint32_t (*s_wcnt)[kGridBins] = sh.wcnt;
+    uint32_t* s_gbase = sh.gbase;
+    uint32_t* s_wsum = sh.wsum;
+    uint64_t* s_key = sh.key;
+    uint32_t* s_id = sh.id;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint64_t lt = lanemask_lt();
-    const uint32_t t = blockIdx.x;
     {
         uint32_t before = 0, all = 0;
         uint32_t i = 0;
@@ -275,6 +290,16 @@ __global__ __launch_bounds__(kGridThreads) void grid_scatter_kernel(const uint64
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(kGridThreads) void grid_scatter_kernel(const uint64_t* __restrict__ key_in,
+                                                                    const uint32_t* __restrict__ id_in,
+                                                                    uint64_t* __restrict__ key_out,
+                                                                    uint32_t* __restrict__ id_out, uint32_t m,
+                                                                    uint32_t tile, uint32_t ntiles, uint32_t shift,
+                                                                    uint32_t mask,
+                                                                    const uint32_t* __restrict__ tile_hist) {
+    __shared__ GridScatterShared sh;
+    grid_scatter_body(key_in, id_in, key_out, id_out, m, tile, ntiles, shift, mask, tile_hist, blockIdx.x, sh);
+}
 
 // ---- ranks from the sorted keys -----------------------------------------------------------------
 // Over the sorted list, position j starts a key run if key[j] != key[j-1] and an r1 run if the
@@ -295,11 +320,14 @@ __device__ __forceinline__ GridFlags grid_flags(uint64_t prev, uint64_t cur, uin
     return f;
 }
 
-__global__ __launch_bounds__(kGridThreads) void grid_rank_reduce_kernel(const uint64_t* __restrict__ key, uint32_t m,
-                                                                        uint32_t tile, uint32_t b2, int round0,
-                                                                        uint32_t* __restrict__ tile_rec) {
-    __shared__ uint32_t s_k[kGridWaves], s_r[kGridWaves], s_n[kGridWaves];
-    const uint32_t t = blockIdx.x;
+struct GridReduceShared {
+    uint32_t k[kGridWaves], r[kGridWaves], n[kGridWaves];
+};
+__device__ __forceinline__ void grid_rank_reduce_body(const uint64_t* key, uint32_t m, uint32_t tile, uint32_t b2, int round0,
+                                                      uint32_t* tile_rec, uint32_t t, GridReduceShared& sh) {
+    uint32_t* s_k = sh.k;
+    uint32_t* s_r = sh.r;
+    uint32_t* s_n = sh.n;
     const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
     uint32_t lastk = 0, lastr = 0, tied = 0;  // run starts as position + 1, 0 = none
     for (uint32_t j = lo + threadIdx.x; j < hi; j += kGridThreads) {
@@ -335,6 +363,12 @@ __global__ __launch_bounds__(kGridThreads) void grid_rank_reduce_kernel(const ui
         tile_rec[4u * t + 2u] = n;
     }
 }
+__global__ __launch_bounds__(kGridThreads) void grid_rank_reduce_kernel(const uint64_t* __restrict__ key, uint32_t m,
+                                                                        uint32_t tile, uint32_t b2, int round0,
+                                                                        uint32_t* __restrict__ tile_rec) {
+    __shared__ GridReduceShared sh;
+    grid_rank_reduce_body(key, m, tile, b2, round0, tile_rec, blockIdx.x, sh);
+}
 
 // One workgroup, one thread per tile: what every tile inherits from the tiles before it.
 __global__ __launch_bounds__(kGridScanThreads) void grid_rank_scan_kernel(uint32_t* __restrict__ tile_rec,
@@ -357,15 +391,12 @@ __global__ __launch_bounds__(kGridScanThreads) void grid_rank_scan_kernel(uint32
     if (t == 0) count[0] = tn;
 }
 
-__global__ __launch_bounds__(kGridThreads) void grid_rank_apply_kernel(GridArgs a, const uint64_t* __restrict__ key,
-                                                                       const uint32_t* __restrict__ id, uint32_t m,
-                                                                       uint32_t tile, uint32_t b2, int round0,
-                                                                       const uint32_t* __restrict__ tile_rec,
-                                                                       uint32_t* __restrict__ id_out) {
-    __shared__ uint32_t s_w[kGridWaves];
-    const uint32_t t = blockIdx.x;
+// cark / carr / carn: what tile t inherits from the tiles before it (last key-run start, last rank-run start,
+// unfinished suffixes).
+__device__ __forceinline__ void grid_rank_apply_body(const GridArgs& a, const uint64_t* key, const uint32_t* id, uint32_t m,
+                                                     uint32_t tile, uint32_t b2, int round0, uint32_t cark, uint32_t carr,
+                                                     uint32_t carn, uint32_t* id_out, uint32_t t, uint32_t* s_w) {
     const uint32_t lo = t * tile, hi = m - lo < tile ? m : lo + tile;
-    uint32_t cark = tile_rec[4u * t + 0u], carr = tile_rec[4u * t + 1u], carn = tile_rec[4u * t + 2u];
     for (uint32_t base = lo; base < hi; base += kGridRankChunk) {
         const uint32_t j0 = base + threadIdx.x * kGridRankVecs;
         uint64_t k[kGridRankVecs + 2];  // key[j0-1 .. j0+kGridRankVecs]
@@ -413,6 +444,16 @@ __global__ __launch_bounds__(kGridThreads) void grid_rank_apply_kernel(GridArgs 
         carn += tn;
     }
 }
+__global__ __launch_bounds__(kGridThreads) void grid_rank_apply_kernel(GridArgs a, const uint64_t* __restrict__ key,
+                                                                       const uint32_t* __restrict__ id, uint32_t m,
+                                                                       uint32_t tile, uint32_t b2, int round0,
+                                                                       const uint32_t* __restrict__ tile_rec,
+                                                                       uint32_t* __restrict__ id_out) {
+    __shared__ uint32_t s_w[kGridWaves];
+    const uint32_t t = blockIdx.x;
+    grid_rank_apply_body(a, key, id, m, tile, b2, round0, tile_rec[4u * t + 0u], tile_rec[4u * t + 1u], tile_rec[4u * t + 2u],
+                         id_out, t, s_w);
+}
 
 // ---- periodic runs: whole groups resolved in one step ------------------------------------------------
 // A group of tied suffixes whose positions form an arithmetic progression i, i+p, i+2p, ... with
@@ -442,23 +483,22 @@ __device__ __forceinline__ uint32_t grid_run_step(const GridArgs& a, uint2 mm, u
     return per;
 }
 
-__global__ __launch_bounds__(kGridThreads) void grid_runs_clear_kernel(GridArgs a, const uint32_t* __restrict__ id,
-                                                                       uint32_t m, uint2* __restrict__ tmm,
-                                                                       uint2* __restrict__ tcs) {
-    const uint32_t nthreads = gridDim.x * kGridThreads;
-    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+__device__ __forceinline__ void grid_runs_clear_body(const GridArgs& a, const uint32_t* id, uint32_t m, uint2* tmm, uint2* tcs, uint32_t first, uint32_t nthreads) {
+    for (uint32_t j = first; j < m; j += nthreads) {
         const uint32_t r = a.rank[id[j]];
         tmm[r] = make_uint2(0xFFFFFFFFu, 0u);
         tcs[r] = make_uint2(0u, 0u);
     }
 }
-
-__global__ __launch_bounds__(kGridThreads) void grid_runs_stats_kernel(GridArgs a, const uint32_t* __restrict__ id,
+__global__ __launch_bounds__(kGridThreads) void grid_runs_clear_kernel(GridArgs a, const uint32_t* __restrict__ id,
                                                                        uint32_t m, uint2* __restrict__ tmm,
                                                                        uint2* __restrict__ tcs) {
-    const uint32_t nthreads = gridDim.x * kGridThreads;
+    grid_runs_clear_body(a, id, m, tmm, tcs, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
+}
+
+__device__ __forceinline__ void grid_runs_stats_body(const GridArgs& a, const uint32_t* id, uint32_t m, uint2* tmm, uint2* tcs, uint32_t first, uint32_t nthreads) {
     const int lane = lane_id();
-    for (uint32_t j0 = blockIdx.x * kGridThreads + (threadIdx.x & ~63u); j0 < m; j0 += nthreads) {
+    for (uint32_t j0 = (first & ~63u); j0 < m; j0 += nthreads) {
         const uint32_t j = j0 + (uint32_t)lane;
         const bool valid = j < m;
         const uint32_t g = id[valid ? j : j0];
@@ -484,26 +524,29 @@ __global__ __launch_bounds__(kGridThreads) void grid_runs_stats_kernel(GridArgs 
         }
     }
 }
-
-__global__ __launch_bounds__(kGridThreads) void grid_runs_check_kernel(GridArgs a, const uint32_t* __restrict__ id,
-                                                                       uint32_t m, uint64_t h,
-                                                                       const uint2* __restrict__ tmm,
+__global__ __launch_bounds__(kGridThreads) void grid_runs_stats_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, uint2* __restrict__ tmm,
                                                                        uint2* __restrict__ tcs) {
-    const uint32_t nthreads = gridDim.x * kGridThreads;
-    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+    grid_runs_stats_body(a, id, m, tmm, tcs, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
+}
+
+__device__ __forceinline__ void grid_runs_check_body(const GridArgs& a, const uint32_t* id, uint32_t m, uint64_t h, const uint2* tmm, uint2* tcs, uint32_t first, uint32_t nthreads) {
+    for (uint32_t j = first; j < m; j += nthreads) {
         const uint32_t g = id[j], r = a.rank[g];
         const uint2 mm = tmm[r];
         const uint32_t per = grid_run_step(a, mm, tcs[r].x, h);
         if (per && (g - mm.x) % per != 0u) atomicOr(&tcs[r].y, kGridRunBad);
     }
 }
-
-__global__ __launch_bounds__(kGridThreads) void grid_runs_break_kernel(GridArgs a, const uint32_t* __restrict__ id,
+__global__ __launch_bounds__(kGridThreads) void grid_runs_check_kernel(GridArgs a, const uint32_t* __restrict__ id,
                                                                        uint32_t m, uint64_t h,
                                                                        const uint2* __restrict__ tmm,
                                                                        uint2* __restrict__ tcs) {
-    const uint32_t nthreads = gridDim.x * kGridThreads;
-    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+    grid_runs_check_body(a, id, m, h, tmm, tcs, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
+}
+
+__device__ __forceinline__ void grid_runs_break_body(const GridArgs& a, const uint32_t* id, uint32_t m, uint64_t h, const uint2* tmm, uint2* tcs, uint32_t first, uint32_t nthreads) {
+    for (uint32_t j = first; j < m; j += nthreads) {
         const uint32_t g = id[j], r = a.rank[g];
         if (j && a.rank[id[j - 1u]] == r) continue;  // not the group's first member
         const uint2 mm = tmm[r];
@@ -525,15 +568,18 @@ __global__ __launch_bounds__(kGridThreads) void grid_runs_break_kernel(GridArgs 
         }
     }
 }
+__global__ __launch_bounds__(kGridThreads) void grid_runs_break_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, uint64_t h,
+                                                                       const uint2* __restrict__ tmm,
+                                                                       uint2* __restrict__ tcs) {
+    grid_runs_break_body(a, id, m, h, tmm, tcs, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
+}
 
 // (count[1] += the suffixes settled: the host reads it with the round's count and tries less often
 // when it stays small)
-__global__ __launch_bounds__(kGridThreads) void grid_runs_apply_kernel(GridArgs a, const uint32_t* __restrict__ id,
-                                                                       uint32_t m, const uint2* __restrict__ tmm,
-                                                                       const uint2* __restrict__ tcs) {
-    const uint32_t nthreads = gridDim.x * kGridThreads;
+__device__ __forceinline__ void grid_runs_apply_body(const GridArgs& a, const uint32_t* id, uint32_t m, const uint2* tmm, const uint2* tcs, uint32_t first, uint32_t nthreads) {
     uint32_t settled = 0;
-    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += nthreads) {
+    for (uint32_t j = first; j < m; j += nthreads) {
         const uint32_t g = id[j], r = a.rank[g];
         const uint2 cs = tcs[r];
         if (!(cs.y & kGridRunDone)) continue;
@@ -547,6 +593,11 @@ __global__ __launch_bounds__(kGridThreads) void grid_runs_apply_kernel(GridArgs 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) settled += __shfl_xor(settled, o);
     if (lane_id() == 0 && settled) atomicAdd(&a.count[1], settled);
+}
+__global__ __launch_bounds__(kGridThreads) void grid_runs_apply_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                       uint32_t m, const uint2* __restrict__ tmm,
+                                                                       const uint2* __restrict__ tcs) {
+    grid_runs_apply_body(a, id, m, tmm, tcs, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
 }
 
 // ---- the last rounds in one launch ----------------------------------------------------------------
@@ -568,11 +619,9 @@ struct GridFinishShared {
     uint32_t wsum[kGridFinishThreads / kWave];
 };
 
-__global__ __launch_bounds__(kGridFinishThreads) void grid_finish_kernel(GridArgs a, const uint32_t* __restrict__ id_in,
-                                                                         uint32_t m, uint64_t h, uint32_t b1,
-                                                                         uint32_t b2) {
+__device__ __forceinline__ void grid_finish_body(const GridArgs& a, const uint32_t* id_in, uint32_t m, uint64_t h, uint32_t b1,
+                                                 uint32_t b2, GridFinishShared& sh) {
     constexpr int NT = kGridFinishThreads, W = NT / kWave, V = kGridFinishVecs;
-    __shared__ GridFinishShared sh;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint64_t lt = lanemask_lt();
     uint64_t k[V];
@@ -702,6 +751,13 @@ __global__ __launch_bounds__(kGridFinishThreads) void grid_finish_kernel(GridArg
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kGridFinishThreads) void grid_finish_kernel(GridArgs a, const uint32_t* __restrict__ id_in,
+                                                                         uint32_t m, uint64_t h, uint32_t b1,
+                                                                         uint32_t b2) {
+    __shared__ GridFinishShared sh;
+    grid_finish_body(a, id_in, m, h, b1, b2, sh);
 }
 
 }  // namespace bwtgpu

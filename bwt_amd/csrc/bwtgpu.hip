@@ -13,6 +13,7 @@
 
 #include "bwt_forward.hpp"
 #include "bwt_forward_grid.hpp"
+#include "bwt_forward_grid_coop.hpp"
 #include "bwt_forward_lds.hpp"
 #include "bwt_forward_small.hpp"
 #include "bwt_inverse.hpp"
@@ -64,6 +65,7 @@ struct Device {
     int cus = 0;
     int fwd_wgs_per_cu = 1;
     int inv_wgs_per_cu = 1;
+    int coop_wgs = 0;  // workgroups of grid_forward_coop_kernel that are resident together (0: no cooperative launches here)
     // grow-only buffers for the host-pointer entry points
     void* d_in = nullptr;   size_t in_cap = 0;
     void* d_out = nullptr;  size_t out_cap = 0;
@@ -478,6 +480,13 @@ int ensure_device(int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bwt_inverse_build_kernel<kInvThreads>, kInvThreads, 0) ==
             hipSuccess && occ > 0)
         d->inv_wgs_per_cu = occ;
+    {
+        int coop = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, grid_forward_coop_kernel, kGridThreads, 0) == hipSuccess && occ > 0)
+            d->coop_wgs = (int)std::min<size_t>((size_t)occ * (size_t)d->cus, kGridMaxTiles);
+        (void)hipGetLastError();
+    }
     HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     // this device's copy of the static scratch array (the device is current here)
     void* sp = nullptr;
@@ -513,8 +522,66 @@ uint32_t grid_tile(uint32_t m) {
     return (uint32_t)tile;
 }
 
+// BWTGPU_GRID_SYNC=host keeps the device-wide path driven from the host (a launch per step, a read-back
+// per round: the call then blocks); the default is the resident kernel (bwt_forward_grid_coop.hpp).
+bool grid_host_driven() {
+    const char* e = std::getenv("BWTGPU_GRID_SYNC");
+    return e && !strcmp(e, "host");
+}
+
+// The device-wide path as two launches, nothing read back: returns BWTGPU_OK once they are enqueued, or
+// 1 if this device cannot launch the resident kernel (the caller then drives the steps from the host).
+int forward_grid_coop(const Device& d, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
+                      uint8_t* d_out, void* d_workspace, hipStream_t s) {
+    if (d.coop_wgs <= 0) return 1;
+    const GridGeom g = grid_geom(total_len, block_size);
+    uint8_t* ws = (uint8_t*)d_workspace;
+    GridCoopArgs c;
+    c.a.in = d_in;
+    c.a.out = d_out;
+    c.a.total_len = total_len;
+    c.a.block_size = (uint32_t)block_size;
+    c.a.nblocks = (uint32_t)((total_len + block_size - 1) / block_size);
+    c.a.delim = delimiter;
+    c.a.rows = (uint32_t)g.rows;
+    c.a.rank = (uint32_t*)(ws + g.rank_off);
+    c.a.presence = (uint32_t*)(ws + g.presence_off);
+    c.a.tile_hist = (uint32_t*)(ws + g.hist_off);
+    c.a.tile_rec = (uint32_t*)(ws + g.rec_off);
+    c.a.count = (uint32_t*)(ws + g.count_off);
+    for (int i = 0; i < 2; ++i) {
+        c.key[i] = (uint64_t*)(ws + g.key_off[i]);
+        c.id[i] = (uint32_t*)(ws + g.id_off[i]);
+    }
+    c.status = (uint32_t*)(ws + 4);   // the header (cleared by the caller): error flags, barrier words, state words
+    c.bar = (uint32_t*)(ws + 384);
+    c.state = (uint32_t*)(ws + 480);
+    HIP_TRY(hipMemsetAsync(ws + g.presence_off, 0, 32, s));
+    HIP_TRY(hipMemsetAsync(ws + g.count_off, 0, 8, s));
+    const uint32_t tile = grid_tile_size(c.a.rows);
+    size_t want = (c.a.rows + tile - 1) / tile;
+    if (const char* e = std::getenv("BWTGPU_COOP_WGS")) want = std::min<size_t>(want, (size_t)std::max(1, atoi(e)));  // experiments
+    const uint32_t nwg = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)d.coop_wgs, want));
+    void* args[] = {&c};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(grid_forward_coop_kernel), dim3(nwg),
+                                                    dim3(kGridThreads), args, 0, s);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    const size_t longest = std::min(total_len, block_size) + 1;
+    hipLaunchKernelGGL(grid_finish_coop_kernel, dim3(1), dim3(kGridFinishThreads), 0, s, c, (uint32_t)bit_length(c.a.rows - 1u),
+                       (uint32_t)bit_length((uint32_t)longest));
+    HIP_TRY(hipGetLastError());
+    return BWTGPU_OK;
+}
+
 int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
                  uint8_t* d_out, void* d_workspace, hipStream_t s) {
+    if (!grid_host_driven()) {
+        const int rc = forward_grid_coop(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
+        if (rc <= 0) return rc;
+    }
     const GridGeom g = grid_geom(total_len, block_size);
     uint8_t* ws = (uint8_t*)d_workspace;
     uint32_t* host = pinned_words();

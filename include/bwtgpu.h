@@ -21,11 +21,10 @@
  *     The on-disk container adds one leading delimiter byte per file
  *     (reference src/bwt.cpp:131-139); that byte is written by the host layer, not here.
  *   - "_device" entry points take device pointers, enqueue on `stream` (a hipStream_t
- *     passed as void*, NULL = the default stream) and return without synchronising
- *     (bwtgpu_forward_batch_device on a batch of few large blocks, or of blocks above
- *     2 MiB - 1, is the exception: it reads small intermediate results back and so blocks
- *     the calling thread for most of its duration; it stays ordered with `stream`); the
- *     others take host pointers and are synchronous.
+ *     passed as void*, NULL = the default stream) and return without synchronising; the
+ *     others take host pointers and are synchronous.  (On a device that cannot launch
+ *     cooperative kernels -- no MI300 / MI355 is one -- bwtgpu_forward_batch_device falls back,
+ *     for batches of few large blocks, to a variant that reads small results back and blocks.)
  */
 #ifndef BWTGPU_H
 #define BWTGPU_H

@@ -641,6 +641,29 @@ def load_mixed():
         return json.load(f)
 
 
+def test_device_wide_path_driven_from_the_host(orc, forward_path):
+    """The device-wide forward path runs as one resident kernel by default; driven from the host (a launch
+    per step, the count read back every round: what a device without cooperative launches falls back to) it
+    gives the same bytes."""
+    if forward_path != "grid":
+        pytest.skip("one route")
+    old = os.environ.get("BWTGPU_GRID_SYNC")
+    os.environ["BWTGPU_GRID_SYNC"] = "host"
+    try:
+        rng = np.random.default_rng(8)
+        text = open(os.path.join(CORPUS, "alice29.txt"), "rb").read()
+        ptt5 = open(os.path.join(CORPUS, "ptt5"), "rb").read()
+        for data, bs in [(text, 131072), (text, 1 << 20), (ptt5[:200000], 65536), (rng.integers(0, 255, size=300000, dtype=np.uint8).tobytes(), 100000),
+                         (synth.generate("acgt", 5, 0, 3 * 262144 + 77).tobytes(), 262144), ((b"abcdefg" * 30000)[:200001], 70000)]:
+            want = orc.forward_buffer(data, bs, 8)
+            assert api.forward_batch(data, bs, want[0]) == want[1:], (len(data), bs)
+    finally:
+        if old is None:
+            os.environ.pop("BWTGPU_GRID_SYNC", None)
+        else:
+            os.environ["BWTGPU_GRID_SYNC"] = old
+
+
 def test_blocks_above_two_mib(orc, forward_path):
     """Blocks too long for the one-workgroup kernels: device-wide forward path, 64-bit inverse
     table words, coarser segments.  Against the oracle at 3 and 5 MiB, by round trip at 48 MiB."""
