@@ -108,6 +108,7 @@ static int forward_single_slab(const char* input_file, const char* output_file, 
         const char delimiter = static_cast<char>(delimiter_byte);
         FileProcessor writer(input_file, output_file, block_size);
         if (!writer.is_open()) break;
+        writer.reserve_output(1 + got + (got + block_size - 1) / block_size);  // header, bytes, one delimiter per block
         const uint8_t* out = nullptr;
         size_t n = 0;
         if (bwtgpu_pipeline_submit(p, 0, got, static_cast<uint8_t>(delimiter)) != BWTGPU_OK ||
@@ -136,9 +137,11 @@ int bwt_forward_process_file(const char* input_file, const char* output_file, si
         if (probe.is_open() && probe.input_is_regular() && probe.input_size() < block_size)
             block_size = probe.input_size() ? probe.input_size() : 1;
     }
+    bwt_host::trace_point("start");
     const int fast = forward_single_slab(input_file, output_file, block_size);
     if (fast >= 0) return fast;
     const int delimiter_byte = find_unique_char(input_file);
+    bwt_host::trace_point("delimiter found");
     if (delimiter_byte == -1) {
         std::cerr << "Error: Cannot find a unique delimiter (all 256 byte values appear in file)" << std::endl;
         return 1;
@@ -156,9 +159,13 @@ int bwt_forward_process_file(const char* input_file, const char* output_file, si
         std::cerr << "Error: short write to the output file" << std::endl;
         return 1;
     }
+    if (processor.input_is_regular())
+        processor.reserve_output(1 + processor.input_size() + (processor.input_size() + block_size - 1) / block_size);
     const int rc = bwt_host::run_slabs(processor, BWTGPU_FORWARD, block_size, static_cast<unsigned char>(delimiter),
                                        processor.input_size());
+    bwt_host::trace_point("slabs done");
     processor.close();
+    bwt_host::trace_point("closed");
     return rc;
 }
 

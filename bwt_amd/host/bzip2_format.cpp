@@ -68,22 +68,32 @@ int Bzip2BWTProcessor::process_file_inverse(const char* input_file, const char* 
         return 1;
     }
     if (block_size == 0) return 0;  // the reference reads nothing per block then and stops at once
-    // every well-formed block up to the end of the input or the first malformed one, as one batch
-    std::vector<unsigned char> last, block;
+    // Well-formed blocks up to the end of the input or the first malformed one go to the GPU in batches of
+    // bounded size (a batch ends early at a short block, which can only be the file's last), so that a
+    // long file needs a batch's worth of host memory and not its own length twice over.
+    const size_t kBatchBytes = (size_t)256 << 20;
+    std::vector<unsigned char> batch, block, text;
     std::vector<uint32_t> rows;
+    auto flush = [&]() -> bool {
+        if (batch.empty()) return true;
+        text.resize(batch.size());
+        if (bwtgpu_inverse_origin_batch(0, batch.data(), batch.size(), block_size, rows.data(), text.data()) != BWTGPU_OK) {
+            std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+            return false;
+        }
+        out.write(reinterpret_cast<const char*>(text.data()), (std::streamsize)text.size());
+        batch.clear();
+        rows.clear();
+        return out.good();
+    };
     int origPtr = 0;
-    bool full = true;  // only the last block of a batch may be short
+    bool full = true;  // only the last block may be short
     while (full && in.good() && read_bzip2_block(in, block_size, origPtr, block)) {
-        last.insert(last.end(), block.begin(), block.end());
+        batch.insert(batch.end(), block.begin(), block.end());
         rows.push_back((uint32_t)origPtr);
         full = block.size() == block_size;
+        if (batch.size() + block_size > kBatchBytes && !flush()) return 1;
     }
-    if (last.empty()) return 0;
-    std::vector<unsigned char> text(last.size());
-    if (bwtgpu_inverse_origin_batch(0, last.data(), last.size(), block_size, rows.data(), text.data()) != BWTGPU_OK) {
-        std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
-        return 1;
-    }
-    out.write(reinterpret_cast<const char*>(text.data()), (std::streamsize)text.size());
+    if (!flush()) return 1;
     return out.good() ? 0 : 1;
 }

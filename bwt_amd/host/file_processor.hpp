@@ -10,8 +10,10 @@
 
 #include <cstddef>
 #include <cstdio>
+#include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 class FileProcessor {
@@ -43,6 +45,13 @@ public:
     // Size of the input file in bytes (0 if it is not a regular file: see input_is_regular()).
     size_t input_size() const;
     bool input_is_regular() const;
+    // Tells the writer how long the output will be (both transforms know it from the input's length).  A
+    // regular output file is then set to that length and mapped, a helper thread allocates its pages
+    // while the first results are still being computed, and write_bytes copies into the mapping from
+    // several threads at once.  (Writes through the file descriptor take the file's lock one at a time.)
+    // Without the call, or if it fails (false), write_bytes goes through the descriptor as before;
+    // output beyond the reservation does too, and close() cuts the file to what was written.
+    bool reserve_output(size_t total_bytes);
 
 private:
     size_t read_bytes_locked(char* dst, size_t max_bytes);  // mutex_ held by the caller
@@ -54,6 +63,13 @@ private:
     bool regular_ = false;
     bool out_regular_ = false;
     std::vector<char> scratch_;
+    // reserve_output's mapping (null: none), its length, bytes written so far, the thread that allocates its pages
+    char* map_ = nullptr;
+    size_t map_len_ = 0, out_pos_ = 0;
+    std::vector<std::thread> prefault_;
+    std::atomic<bool> stop_prefault_{false};
+    std::atomic<size_t> allocated_{0};  // bytes from the file's start whose pages exist (or one of two end marks)
+    void drop_mapping_locked();  // out_mutex_ held: back to the descriptor, positioned after what was written
     // The reference guards both streams with one lock (src/file_processor.hpp:45); here each stream has
     // its own, so that the thread that reads slabs and the thread that writes results do not wait for
     // each other.  Every method is still safe to call from any thread.

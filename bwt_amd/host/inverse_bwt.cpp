@@ -45,8 +45,13 @@ int bwt_inverse_process_file(const char* input_file, const char* output_file, si
     // a block size beyond the file: the body is one chunk of its own length
     if (block_size > BWTGPU_MAX_BLOCK_SIZE && processor.input_is_regular() && body >= 1 && body - 1 < block_size)
         block_size = body > 1 ? body - 1 : 1;
+    if (processor.input_is_regular() && body > 0)  // every block of block_size + 1 bytes gives up its delimiter
+        processor.reserve_output(body - (body + block_size) / (block_size + 1));
+    bwt_host::trace_point("start");
     const int rc = bwt_host::run_slabs(processor, BWTGPU_INVERSE, block_size, static_cast<unsigned char>(delimiter), body);
+    bwt_host::trace_point("slabs done");
     processor.close();
+    bwt_host::trace_point("closed");
     return rc;
 }
 

@@ -32,6 +32,13 @@
 
 namespace bwt_host {
 
+// BWT_HOST_TRACE=1: "bwt host: +<seconds since the program's first call here> <what>" on stderr
+inline void trace_point(const char* what) {
+    static const bool on = std::getenv("BWT_HOST_TRACE") != nullptr;
+    static const auto t0 = std::chrono::steady_clock::now();
+    if (on) std::fprintf(stderr, "bwt host: +%.3f s %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+
 // GPUs to spread slabs over: BWT_DEVICES (default 1), capped by what the library bound.
 inline int device_budget() {
     const int have = bwtgpu_init(0);
@@ -44,10 +51,24 @@ inline int device_budget() {
     return want < have ? want : have;
 }
 
+// Most bytes in a slab: BWT_SLAB_MIB, default 64.  A long file goes through many slabs of this size: the
+// four pinned buffers of a pipeline (two slots, in and out) are then touched for the first time during
+// the first two slabs only and stay mapped for the rest, and reading, transfers, kernels and writing of
+// neighbouring slabs overlap.  (Slabs of 512 MiB made every write the first touch of its buffer:
+// 0.24 s per slab in page faults.)
+inline size_t slab_max_bytes() {
+    static const size_t n = [] {
+        const char* e = std::getenv("BWT_SLAB_MIB");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v >= 1 && v <= 4096 ? v : 64) << 20;
+    }();
+    return n;
+}
+
 // Blocks per slab: enough blocks to fill every compute unit several times over, within a
 // bounded pinned-memory footprint, and no more than the file needs.
 inline size_t slab_blocks_for(size_t unit_bytes, size_t file_bytes) {
-    const size_t kTargetBlocks = 2048, kMinBytes = (size_t)16 << 20, kMaxBytes = (size_t)512 << 20;
+    const size_t kTargetBlocks = 2048, kMinBytes = (size_t)16 << 20, kMaxBytes = slab_max_bytes();
     size_t blocks = kTargetBlocks;
     if (blocks * unit_bytes < kMinBytes) blocks = (kMinBytes + unit_bytes - 1) / unit_bytes;
     if (blocks * unit_bytes > kMaxBytes) blocks = kMaxBytes / unit_bytes;
@@ -300,6 +321,7 @@ inline int run_slabs_threaded(FileProcessor& processor, int direction, size_t bl
             }
             t_wait += t1 - t0;
             t_write += now() - t1;
+            if (trace) std::fprintf(stderr, "bwt host: slab %zu: %zu bytes, waited %.3f s, wrote in %.3f s\n", k, n, t1 - t0, now() - t1);
             std::lock_guard<std::mutex> lock(mu);
             slot_of(k).st = Free;
             cv.notify_all();
@@ -322,6 +344,7 @@ inline int run_slabs_threaded(FileProcessor& processor, int direction, size_t bl
                 fail_with(bwtgpu_last_error());
                 break;
             }
+            trace_point("pipeline ready");
             threads.emplace_back(submitter, dev);
         }
         bwtgpu_pipeline* p = pipes[(size_t)dev];

@@ -151,6 +151,12 @@ def test_threaded_runner_reports_errors(tmp_path):
     raw.tofile(f)
     r = run([os.path.join(BUILD, "inverse_bwt"), f, b, "512"])
     assert r.returncode == 1 and "delimiter" in r.stderr
+    # the output was set to its full length up front: what is left is only what was written
+    got = np.fromfile(b, dtype=np.uint8)
+    assert got.size < data.size and np.array_equal(got, data[:got.size])
+    # a device node as the output: nothing to reserve, plain writes
+    assert run([os.path.join(BUILD, "inverse_bwt"), str(tmp_path / "d.good.bwt"), "/dev/null", "512"]).returncode == 1  # no such input
+    assert run([os.path.join(BUILD, "bwt"), src, "/dev/null", "512"]).returncode == 0
 
 
 def _sample_blocks_equal_oracle(data, out, bs, delim, blocks):

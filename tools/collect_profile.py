@@ -29,7 +29,7 @@ def algorithmic_bytes(kernel: str, n: int, nb: int):
     rows = n + nb
     if "bwt_forward_kernel" in kernel or "bwt_forward_small" in kernel or "bwt_forward_lds_kernel" in kernel:
         return n + rows  # text in, transformed blocks out
-    if "inverse_packed_kernel" in kernel:
+    if "inverse_packed_kernel" in kernel or "inverse_t16_kernel" in kernel:
         return rows + n  # transformed bytes in, text out: everything between stays in LDS
     if "inverse_packed_classify" in kernel:
         return None  # one cache line per block
