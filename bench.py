@@ -8,7 +8,7 @@ on the data path -- blocks are independent).
 A "step" is one forward pass plus one inverse pass of the hot path over the rank's whole
 shard.  Rank 0 prints ONE JSON line.  `value` is input bytes of all ranks per second of
 (forward + inverse), GB = 1e9 bytes.  `roofline` prices the dominant kernel (the forward
-suffix-sort kernel) at its algorithmic bytes (read N, write N + nblocks per launch) over
+suffix-sort kernel, bwt_forward_lds_kernel on the headline workload) at its algorithmic bytes (read N, write N + nblocks per launch) over
 its HIP-event duration; `cpu_baseline` times the reference CPU implementation on a bounded
 sample of the same workload on this host's cores.  Beside the headline the line carries
   other_workloads   the other benchmark configurations (each with its own roofline entries, and the
@@ -260,8 +260,8 @@ def main() -> None:
         N + nblocks; inverse the other way round) over the HIP-event time of the pass on its stream."""
         algo = 2 * nbytes + nblocks
         out = {}
-        for key, ms, what in (("roofline", fwd_ms, "forward pass (all its launches: bwt_forward_kernel x2, or the device-wide path for few large blocks)"),
-                              ("roofline_inverse", inv_ms, "inverse pass (all its launches: in-LDS inverse of blocks over at most four symbols; table build, walk, stitch, place for the others)")):
+        for key, ms, what in (("roofline", fwd_ms, "forward pass (all its launches: bwt_forward_lds_kernel for blocks whose text fits the LDS, bwt_forward_kernel x2 behind it for the rest; the device-wide resident kernel for few large blocks)"),
+                              ("roofline_inverse", inv_ms, "inverse pass (all its launches: bwt_inverse_packed_kernel for blocks over at most four symbols and bwt_inverse_t16_kernel for blocks of at most 64 KiB, both inside the LDS; table build, walk, stitch, place for the others)")):
             out[key] = {"bound": "hbm", "kernel": what, "achieved": algo / (ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": algo / (ms * 1e-3) / HBM_PEAK,
                         "traffic": None, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": ms}

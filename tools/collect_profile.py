@@ -125,11 +125,13 @@ def main():
                 k["algorithmic_bytes"] = k["algorithmic_GBps"] = k["frac_of_hbm_peak"] = None
                 k["note"] = "finds every block finished by an earlier kernel and returns"
         rows.sort(key=lambda k: -k["avg_launch_ms"] * k["launches_per_pass"])
-        # the two forward instantiations share one pass's bytes: price them on the one that did the work
-        fw = [k for k in rows if k["name"].startswith("bwt_forward_kernel") and k["algorithmic_bytes"] is not None]
-        for k in fw[1:] if fw else []:
-            if k["avg_launch_ms"] * k["launches_per_pass"] < 0.05 * fw[0]["avg_launch_ms"] * fw[0]["launches_per_pass"]:
-                k["algorithmic_bytes"] = k["algorithmic_GBps"] = k["frac_of_hbm_peak"] = None
+        # The forward launches of a pass share the pass's bytes (the text-in-LDS kernel hands the blocks it cannot
+        # take, or only samples, to the general kernel behind it): the figures go to the launch that took the most
+        # time, the others say so.
+        fw = [k for k in rows if k["name"].startswith("bwt_forward_") and k["algorithmic_bytes"] is not None]
+        for k in fw[1:]:
+            k["algorithmic_bytes"] = k["algorithmic_GBps"] = k["frac_of_hbm_peak"] = None
+            k["note"] = "same pass and bytes as %s, which is where they are priced" % fw[0]["name"]
         kernels[wl] = {"source": "profiles/%s_kernel_stats_%s.csv + profiles/%s_pmc_%s.json" % (tag, wl, tag, wl),
                        "kernels": rows}
         traffic[wl] = {"forward": tot["forward"], "inverse": tot["inverse"], "source": tag}
