@@ -16,7 +16,7 @@ LDFLAGS  := -Lbwt_amd -lbwtgpu -Wl,-rpath,'$$ORIGIN/../bwt_amd' -pthread
 
 MAIN_EXECS := $(BUILD)/bwt $(BUILD)/inverse_bwt
 TEST_EXECS := $(BUILD)/test_small $(BUILD)/test_medium $(BUILD)/test_bzip2_format
-PERF_EXECS := $(BUILD)/performance
+PERF_EXECS := $(BUILD)/performance $(BUILD)/compare_bwt_performance
 TEST_LIB_OBJS := $(BUILD)/src_test/bwt.o $(BUILD)/src_test/inverse_bwt.o $(BUILD)/src_test/file_processor.o \
                  $(BUILD)/src_test/bzip2_format.o
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/bwtgpu.h
@@ -54,7 +54,8 @@ test: $(TEST_EXECS)
 
 performance: $(PERF_EXECS)
 	@echo "\n=== Running Performance Benchmarks ==="
-	@for t in $(PERF_EXECS); do echo "\n--- $$t ---"; ./$$t || exit 1; done
+	@echo "\n--- $(BUILD)/performance ---"; ./$(BUILD)/performance || exit 1
+	@echo "\n--- $(BUILD)/compare_bwt_performance ---"; ./$(BUILD)/compare_bwt_performance data/canterbury_corpus/alice29.txt || exit 1
 
 clean:
 	@echo "Cleaning..."

@@ -42,6 +42,7 @@ SYMBOLS = [
     "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
     "bwtgpu_pipeline_upload_presence", "bwtgpu_forward_batch_static", "bwtgpu_time_resident",
     "bwtgpu_inverse_origin_workspace_bytes", "bwtgpu_inverse_origin_batch_device", "bwtgpu_inverse_origin_batch",
+    "bwtgpu_forward_origin_workspace_bytes", "bwtgpu_forward_origin_batch_device", "bwtgpu_forward_origin_batch",
 ]
 STATIC_SCRATCH_BYTES = 64 << 20
 
@@ -88,6 +89,12 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_inverse_origin_batch_device.restype = _i
     L.bwtgpu_inverse_origin_batch.argtypes = [_i, _vp, _sz, _sz, _vp, _vp]
     L.bwtgpu_inverse_origin_batch.restype = _i
+    L.bwtgpu_forward_origin_workspace_bytes.argtypes = [_i, _sz, _sz]
+    L.bwtgpu_forward_origin_workspace_bytes.restype = _sz
+    L.bwtgpu_forward_origin_batch_device.argtypes = [_i, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]
+    L.bwtgpu_forward_origin_batch_device.restype = _i
+    L.bwtgpu_forward_origin_batch.argtypes = [_i, _vp, _sz, _sz, _vp, _vp]
+    L.bwtgpu_forward_origin_batch.restype = _i
     L.bwtgpu_inverse_batch_device.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, _vp, _vp, _sz, _vp]
     L.bwtgpu_inverse_batch_device.restype = _i
     L.bwtgpu_inverse_batch.argtypes = [_i, _vp, _sz, _sz, _u8, _vp, ctypes.POINTER(_sz)]
@@ -260,6 +267,33 @@ def inverse_origin_batch(last_columns, block_size: int, orig_ptrs, device: int =
     check(lib().bwtgpu_inverse_origin_batch(device, a.ctypes.data if a.size else None, a.size, block_size,
                                             p.ctypes.data if p.size else None, out.ctypes.data))
     return out[:a.size].tobytes()
+
+
+def forward_origin_batch(data, block_size: int, device: int = 0):
+    """Texts (block i at i*block_size) -> (last columns of their sorted rotations back to back, the row of
+    each block's text): what the reference's process_block produces per block
+    (util/bzip2_bwt_utils.cpp:104-136)."""
+    a = _as_u8(data)
+    if block_size <= 0:
+        raise BwtGpuError(ERR_INVALID, "block_size must be greater than 0")
+    nb = (a.size + block_size - 1) // block_size
+    out = np.empty(max(1, a.size), dtype=np.uint8)
+    rows = np.zeros(max(1, nb), dtype=np.uint32)
+    check(lib().bwtgpu_forward_origin_batch(device, a.ctypes.data if a.size else None, a.size, block_size,
+                                            out.ctypes.data, rows.ctypes.data))
+    return out[:a.size].tobytes(), rows[:nb]
+
+
+def build_origin_container(last_columns, block_size: int, rows) -> bytes:
+    """(last columns, origin rows) -> the container parse_origin_container reads (reference
+    util/bzip2_bwt_utils.cpp:137-155)."""
+    a = _as_u8(last_columns)
+    parts = []
+    for i, row in enumerate(rows):
+        row = int(row)
+        parts.append(bytes([0xFF, (row >> 16) & 0xFF, (row >> 8) & 0xFF, row & 0xFF]))
+        parts.append(a[i * block_size:(i + 1) * block_size].tobytes())
+    return b"".join(parts)
 
 
 def parse_origin_container(raw, block_size: int):

@@ -23,6 +23,14 @@
 //               again; ties of the new key share rank[g] + (offset of the tie inside the old
 //               tie); h doubles until nothing is tied.
 // The order is the reference's (unsigned bytes, shorter suffix first), so the bytes are the same.
+//
+// GridArgs::cyclic selects the other block format this library reads and writes, that of the reference's
+// bzip2 comparison tool (util/bzip2_bwt_utils.cpp:104-136: the block's ROTATIONS sorted, their last column,
+// and the row of rotation 0): no delimiter row (block b owns rows [b block_size, ...)), every symbol and
+// every second rank read modulo the block's length, so nothing is ever "past the end".  Rotations that
+// are equal (a block that is a shorter string repeated) stay tied for ever: doubling stops once
+// h >= the block length, and the tied ones are ranked by position (grid_cyclic_settle_*), rotation 0
+// first among its equals.
 #pragma once
 #include "bwt_device.hpp"
 
@@ -52,6 +60,7 @@ struct GridArgs {
     uint32_t* tile_hist;  // kGridBins * kGridMaxTiles words
     uint32_t* tile_rec;   // 4 * kGridMaxTiles words
     uint32_t* count;      // [0] suffixes still tied after the round, [1] suffixes settled as periodic runs since the host last looked
+    uint32_t cyclic;      // 1: rotations instead of suffixes (no delimiter rows; rows = total_len)
 };
 
 // Row-space position -> block, offset in the block's text (len = the delimiter's position).
@@ -60,12 +69,20 @@ struct GridPos {
 };
 __device__ __forceinline__ GridPos grid_pos(const GridArgs& a, uint32_t g) {
     GridPos p;
-    const uint32_t unit = a.block_size + 1u;
+    const uint32_t unit = a.block_size + (a.cyclic ? 0u : 1u);
     p.b = g / unit;
     p.off = g - p.b * unit;
     const uint64_t rem = a.total_len - (uint64_t)p.b * a.block_size;
     p.len = rem < a.block_size ? (uint32_t)rem : a.block_size;
     return p;
+}
+
+// The output byte of the suffix (rotation) at p: the byte before it -- the delimiter (the block's last byte)
+// for offset 0.
+__device__ __forceinline__ uint8_t grid_prev_byte(const GridArgs& a, const GridPos& p) {
+    const uint8_t* __restrict__ s = a.in + (uint64_t)p.b * a.block_size;
+    if (p.off) return s[p.off - 1u];
+    return a.cyclic ? s[p.len - 1u] : (uint8_t)a.delim;
 }
 
 // Exclusive running maximum of one value per thread over the workgroup (0 for thread 0);
@@ -109,7 +126,7 @@ __device__ __forceinline__ void grid_keys0_body(const GridArgs& a, uint64_t* __r
 #pragma unroll
         for (uint32_t w = 0; w < 8; ++w) {
             uint32_t m = a.presence[w];
-            if ((a.delim >> 5) == w) m |= 1u << (a.delim & 31u);
+            if (!a.cyclic && (a.delim >> 5) == w) m |= 1u << (a.delim & 31u);
             if (w < (c >> 5)) below += __popc(m);
             else if (w == (c >> 5)) below += __popc(m & ((1u << (c & 31u)) - 1u));
         }
@@ -121,10 +138,18 @@ __device__ __forceinline__ void grid_keys0_body(const GridArgs& a, uint64_t* __r
         const GridPos p = grid_pos(a, g);
         const uint8_t* __restrict__ s = a.in + (uint64_t)p.b * a.block_size;
         uint64_t k = p.b;
-        for (uint32_t i = 0; i < m0; ++i) {
-            const uint32_t q = p.off + i;
-            const uint32_t c = q < p.len ? s_code[s[q]] : q == p.len ? dcode : 0u;
-            k = (k << sbits) | c;
+        if (a.cyclic) {
+            uint32_t q = p.off;  // m0 <= the block's length
+            for (uint32_t i = 0; i < m0; ++i) {
+                k = (k << sbits) | s_code[s[q]];
+                q = q + 1u == p.len ? 0u : q + 1u;
+            }
+        } else {
+            for (uint32_t i = 0; i < m0; ++i) {
+                const uint32_t q = p.off + i;
+                const uint32_t c = q < p.len ? s_code[s[q]] : q == p.len ? dcode : 0u;
+                k = (k << sbits) | c;
+            }
         }
         key[g] = k;
         id[g] = g;
@@ -137,6 +162,15 @@ __global__ __launch_bounds__(kGridThreads) void grid_keys0_kernel(GridArgs a, ui
     grid_keys0_body(a, key, id, m0, sbits, s_code, blockIdx.x * kGridThreads + threadIdx.x, gridDim.x * kGridThreads);
 }
 
+// Second half of a later key: rank of the suffix h further on, relative to the block, + 1; 0 past the
+// block's end.  Rotations wrap around instead.
+__device__ __forceinline__ uint32_t grid_second_rank(const GridArgs& a, uint32_t g, const GridPos& p, uint64_t h) {
+    const uint32_t base = g - p.off;
+    if (a.cyclic) return a.rank[base + (uint32_t)(((uint64_t)p.off + h) % p.len)] - base + 1u;
+    if ((uint64_t)p.off + h <= (uint64_t)p.len) return a.rank[g + (uint32_t)h] - base + 1u;
+    return 0u;
+}
+
 // ---- later keys --------------------------------------------------------------------------------
 // key[j] = rank[g] << b2 | (rank[g+h] - first row of the block + 1, or 0 past the block's end).
 __device__ __forceinline__ void grid_keys_body(const GridArgs& a, const uint32_t* id, uint32_t m, uint64_t h, uint32_t b2,
@@ -144,10 +178,7 @@ __device__ __forceinline__ void grid_keys_body(const GridArgs& a, const uint32_t
     for (uint32_t j = first; j < m; j += nthreads) {
         const uint32_t g = id[j];
         const GridPos p = grid_pos(a, g);
-        const uint32_t base = g - p.off;
-        uint32_t r2 = 0;
-        if ((uint64_t)p.off + h <= (uint64_t)p.len) r2 = a.rank[g + (uint32_t)h] - base + 1u;
-        key[j] = ((uint64_t)a.rank[g] << b2) | r2;
+        key[j] = ((uint64_t)a.rank[g] << b2) | grid_second_rank(a, g, p, h);
     }
 }
 __global__ __launch_bounds__(kGridThreads) void grid_keys_kernel(GridArgs a, const uint32_t* __restrict__ id,
@@ -432,8 +463,7 @@ __device__ __forceinline__ void grid_rank_apply_body(const GridArgs& a, const ui
                 const uint32_t g = id[j];
                 a.rank[g] = nr;
                 if (f[i].single) {
-                    const GridPos p = grid_pos(a, g);
-                    a.out[nr] = p.off ? a.in[(uint64_t)p.b * a.block_size + p.off - 1u] : (uint8_t)a.delim;
+                    a.out[nr] = grid_prev_byte(a, grid_pos(a, g));
                 } else {
                     id_out[slot++] = g;
                 }
@@ -587,8 +617,7 @@ __device__ __forceinline__ void grid_runs_apply_body(const GridArgs& a, const ui
         const uint32_t per = cs.y >> 8, k = (g - tmm[r].x) / per;
         const uint32_t nr = r + ((cs.y & kGridRunAsc) ? k : cs.x - 1u - k);
         a.rank[g] = nr;
-        const GridPos p = grid_pos(a, g);
-        a.out[nr] = p.off ? a.in[(uint64_t)p.b * a.block_size + p.off - 1u] : (uint8_t)a.delim;
+        a.out[nr] = grid_prev_byte(a, grid_pos(a, g));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) settled += __shfl_xor(settled, o);
@@ -631,7 +660,8 @@ __device__ __forceinline__ void grid_finish_body(const GridArgs& a, const uint32
         const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
         ids[v] = e < m ? id_in[e] : 0u;
     }
-    for (int round = 0; m && round < 64; ++round, h *= 2) {
+    const uint64_t h_end = a.cyclic ? (uint64_t)min((uint64_t)a.block_size, a.total_len) : ~0ull;  // rotations tied at this depth are equal
+    for (int round = 0; m && round < 64 && h < h_end; ++round, h *= 2) {
         // keys of the round
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -639,10 +669,7 @@ __device__ __forceinline__ void grid_finish_body(const GridArgs& a, const uint32
             k[v] = 0;
             if (e < m) {
                 const uint32_t g = ids[v];
-                const GridPos p = grid_pos(a, g);
-                uint32_t r2 = 0;
-                if ((uint64_t)p.off + h <= (uint64_t)p.len) r2 = a.rank[g + (uint32_t)h] - (g - p.off) + 1u;
-                k[v] = ((uint64_t)a.rank[g] << b2) | r2;
+                k[v] = ((uint64_t)a.rank[g] << b2) | grid_second_rank(a, g, grid_pos(a, g), h);
             }
         }
         // LSD radix sort, the list going from registers through LDS back to registers every pass
@@ -734,8 +761,7 @@ __device__ __forceinline__ void grid_finish_body(const GridArgs& a, const uint32
                 const uint32_t g = gs[i];
                 a.rank[g] = nr;
                 if (f[i].single) {
-                    const GridPos p = grid_pos(a, g);
-                    a.out[nr] = p.off ? a.in[(uint64_t)p.b * a.block_size + p.off - 1u] : (uint8_t)a.delim;
+                    a.out[nr] = grid_prev_byte(a, grid_pos(a, g));
                 } else {
                     sh.id[slot++] = g;
                 }
@@ -751,6 +777,65 @@ __device__ __forceinline__ void grid_finish_body(const GridArgs& a, const uint32
         }
         __syncthreads();
     }
+    if (a.cyclic && m) {
+        // Equal rotations: the list holds them group by group (ascending rank), each group in ascending
+        // position (every sort and every compaction above is stable).  Final rank = the group's + the place in it.
+        uint32_t* const rk = reinterpret_cast<uint32_t*>(sh.key);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+            if (e < m) rk[e] = a.rank[ids[v]];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t e = (uint32_t)((w * V + v) * kWave + lane);
+            if (e < m) {
+                const uint32_t r = rk[e];
+                uint32_t lo = 0, hi = e;  // first list index with this rank
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (rk[mid] < r) lo = mid + 1u;
+                    else hi = mid;
+                }
+                const uint32_t nr = r + (e - lo), g = ids[v];
+                a.rank[g] = nr;
+                a.out[nr] = grid_prev_byte(a, grid_pos(a, g));
+            }
+        }
+    }
+}
+
+// Equal rotations left in a list too long for one workgroup: the same in two steps (the first reads every
+// rank before the second changes any).  place[j] = list index of the first member of j's group.
+__global__ __launch_bounds__(kGridThreads) void grid_cyclic_settle_find_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                               uint32_t m, uint32_t* __restrict__ place) {
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += gridDim.x * kGridThreads) {
+        const uint32_t r = a.rank[id[j]];
+        uint32_t lo = 0, hi = j;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.rank[id[mid]] < r) lo = mid + 1u;
+            else hi = mid;
+        }
+        place[j] = lo;
+    }
+}
+__global__ __launch_bounds__(kGridThreads) void grid_cyclic_settle_apply_kernel(GridArgs a, const uint32_t* __restrict__ id,
+                                                                                uint32_t m, const uint32_t* __restrict__ place) {
+    for (uint32_t j = blockIdx.x * kGridThreads + threadIdx.x; j < m; j += gridDim.x * kGridThreads) {
+        const uint32_t g = id[j];
+        const uint32_t nr = a.rank[g] + (j - place[j]);
+        // (a.rank[g] of a group's first member does not change, and only its own entry is read here)
+        a.rank[g] = nr;
+        a.out[nr] = grid_prev_byte(a, grid_pos(a, g));
+    }
+}
+
+// rows[b] = the row of block b's rotation 0 among the block's sorted rotations.
+__global__ __launch_bounds__(kGridThreads) void grid_cyclic_origin_kernel(GridArgs a, uint32_t* __restrict__ rows) {
+    for (uint32_t b = blockIdx.x * kGridThreads + threadIdx.x; b < a.nblocks; b += gridDim.x * kGridThreads)
+        rows[b] = a.rank[b * a.block_size] - b * a.block_size;
 }
 
 __global__ __launch_bounds__(kGridFinishThreads) void grid_finish_kernel(GridArgs a, const uint32_t* __restrict__ id_in,

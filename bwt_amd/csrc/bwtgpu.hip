@@ -208,9 +208,9 @@ struct GridGeom {
     size_t presence_off, count_off, hist_off, rec_off, rank_off, key_off[2], id_off[2], bytes;
 };
 
-GridGeom grid_geom(size_t total_len, size_t block_size) {
+GridGeom grid_geom(size_t total_len, size_t block_size, bool cyclic = false) {
     GridGeom g;
-    g.rows = total_len + (total_len + block_size - 1) / block_size;
+    g.rows = total_len + (cyclic ? 0 : (total_len + block_size - 1) / block_size);
     size_t off = kHeaderBytes;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -549,6 +549,7 @@ int forward_grid_coop(const Device& d, const uint8_t* d_in, size_t total_len, si
     c.a.tile_hist = (uint32_t*)(ws + g.hist_off);
     c.a.tile_rec = (uint32_t*)(ws + g.rec_off);
     c.a.count = (uint32_t*)(ws + g.count_off);
+    c.a.cyclic = 0;
     for (int i = 0; i < 2; ++i) {
         c.key[i] = (uint64_t*)(ws + g.key_off[i]);
         c.id[i] = (uint32_t*)(ws + g.id_off[i]);
@@ -576,13 +577,16 @@ int forward_grid_coop(const Device& d, const uint8_t* d_in, size_t total_len, si
     return BWTGPU_OK;
 }
 
+// d_rows != nullptr: rotations instead of suffixes (no delimiter; d_out takes total_len bytes, d_rows the row of
+// every block's rotation 0).  That variant is always driven from the host.
 int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
-                 uint8_t* d_out, void* d_workspace, hipStream_t s) {
-    if (!grid_host_driven()) {
+                 uint8_t* d_out, void* d_workspace, hipStream_t s, uint32_t* d_rows = nullptr) {
+    const bool cyclic = d_rows != nullptr;
+    if (!cyclic && !grid_host_driven()) {
         const int rc = forward_grid_coop(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
         if (rc <= 0) return rc;
     }
-    const GridGeom g = grid_geom(total_len, block_size);
+    const GridGeom g = grid_geom(total_len, block_size, cyclic);
     uint8_t* ws = (uint8_t*)d_workspace;
     uint32_t* host = pinned_words();
     if (!host) return fail(BWTGPU_ERR_HIP, "hipHostMalloc of the result words failed");
@@ -599,6 +603,7 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     a.tile_hist = (uint32_t*)(ws + g.hist_off);
     a.tile_rec = (uint32_t*)(ws + g.rec_off);
     a.count = (uint32_t*)(ws + g.count_off);
+    a.cyclic = cyclic ? 1u : 0u;
     uint64_t* key[2] = {(uint64_t*)(ws + g.key_off[0]), (uint64_t*)(ws + g.key_off[1])};
     uint32_t* id[2] = {(uint32_t*)(ws + g.id_off[0]), (uint32_t*)(ws + g.id_off[1])};
 
@@ -610,12 +615,12 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host, ws + g.presence_off, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    host[delimiter >> 5] |= 1u << (delimiter & 31);
+    if (!cyclic) host[delimiter >> 5] |= 1u << (delimiter & 31);
     uint32_t sigma = 0;
     for (int i = 0; i < 8; ++i) sigma += (uint32_t)__builtin_popcount(host[i]);
     const int sbits = bit_length(sigma);                       // codes 1 .. sigma
     const int bbits = bit_length(a.nblocks - 1u);
-    const size_t longest = std::min(total_len, block_size) + 1;  // symbols of the longest block, delimiter included
+    const size_t longest = std::min(total_len, block_size) + (cyclic ? 0 : 1);  // symbols of the longest block, delimiter included
     int m0 = std::max(1, (40 - bbits) / sbits);                // five 8-bit passes
     m0 = (int)std::min<size_t>((size_t)m0, longest);
     const int b1 = bit_length(a.rows - 1u), b2 = bit_length((uint32_t)longest);
@@ -667,11 +672,19 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
     uint32_t runs_m = 0, runs_wait = 0, runs_backoff = 1;
     for (int round = 0; m; ++round) {
         if (round >= 64 || m > a.rows) return fail(BWTGPU_ERR_INTERNAL, "device-wide suffix sort did not converge");
+        if (cyclic && h >= longest && m > kGridFinishCap) {  // what is still tied now are equal rotations: by position
+            const dim3 grid(stream_grid(d, m, kGridThreads * 4)), block(kGridThreads);
+            uint32_t* place = (uint32_t*)key[cur];  // idle between the rank step and the next keys
+            hipLaunchKernelGGL(grid_cyclic_settle_find_kernel, grid, block, 0, s, a, id[cur], m, place);
+            hipLaunchKernelGGL(grid_cyclic_settle_apply_kernel, grid, block, 0, s, a, id[cur], m, place);
+            HIP_TRY(hipGetLastError());
+            break;
+        }
         // The periodic-run step: when a round has left the list nearly as long as it was (right after
         // the first sort: only if hardly anything is settled), and less and less often while it finds little.
         const bool stalled = round == 0 ? (uint64_t)m * 50 > (uint64_t)m_before * 49 : (uint64_t)m * 10 > (uint64_t)m_before * 9;
         if (runs_wait) --runs_wait;
-        else if (m > kGridFinishCap && stalled) {
+        else if (m > kGridFinishCap && stalled && !cyclic) {  // (the run step reasons about a block's end, which rotations lack)
             const dim3 grid(stream_grid(d, m, kGridThreads * 4)), block(kGridThreads);
             uint2* tmm = (uint2*)key[cur];        // both key buffers are idle between the rank step and the next keys
             uint2* tcs = (uint2*)key[cur ^ 1];
@@ -704,6 +717,10 @@ int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t 
         }
         if (trace) fprintf(stderr, "bwtgpu grid forward: depth %llu, %u tied\n", (unsigned long long)(2 * h), m);
         h *= 2;
+    }
+    if (cyclic) {
+        hipLaunchKernelGGL(grid_cyclic_origin_kernel, dim3(stream_grid(d, a.nblocks, kGridThreads)), dim3(kGridThreads), 0, s, a, d_rows);
+        HIP_TRY(hipGetLastError());
     }
     return BWTGPU_OK;
 }
@@ -1148,6 +1165,68 @@ int bwtgpu_inverse_origin_batch_device(int device, const uint8_t* d_in, size_t t
     }
     return inverse_launch(device, d_in, total_len, block_size - 1, 256u, d_orig_ptr, d_out, d_out_lens, d_workspace,
                           workspace_bytes, stream);
+}
+
+// ---- forward of origin-pointer blocks: rotations sorted by the device-wide path ------------------
+size_t bwtgpu_forward_origin_workspace_bytes(int device, size_t total_len, size_t block_size) {
+    if (check_device(device) != BWTGPU_OK || block_size == 0 || total_len == 0 || total_len > kGridMaxRows) return 0;
+    return grid_geom(total_len, std::min(block_size, total_len), true).bytes;
+}
+
+int bwtgpu_forward_origin_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                       uint8_t* d_out, uint32_t* d_rows, void* d_workspace, size_t workspace_bytes,
+                                       void* stream) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (total_len == 0) return BWTGPU_OK;
+    block_size = std::min(block_size, total_len);
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE)
+        return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu exceeds the supported maximum %zu", block_size,
+                    (size_t)BWTGPU_MAX_BLOCK_SIZE);
+    if (total_len > kGridMaxRows) return fail(BWTGPU_ERR_INVALID, "at most 2^31 bytes per batch (%zu given): split it", total_len);
+    if (!d_in || !d_out || !d_rows || !d_workspace) return fail(BWTGPU_ERR_INVALID, "null device pointer");
+    const size_t need = grid_geom(total_len, block_size, true).bytes;
+    if (workspace_bytes < need)
+        return fail(BWTGPU_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
+    return forward_grid(*g_dev[device], d_in, total_len, block_size, 0, d_out, d_workspace, s, d_rows);
+}
+
+int bwtgpu_forward_origin_batch(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t* out,
+                                uint32_t* rows) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
+    if (total_len == 0) return BWTGPU_OK;
+    if (!in || !out || !rows) return fail(BWTGPU_ERR_INVALID, "null host pointer");
+    block_size = std::min(block_size, total_len);
+    if (block_size > BWTGPU_MAX_BLOCK_SIZE) return fail(BWTGPU_ERR_BLOCK_TOO_LARGE, "block_size %zu too large", block_size);
+    Device& d = *g_dev[device];
+    std::lock_guard<std::mutex> lock(d.mu);
+    HIP_TRY(hipSetDevice(device));
+    // sub-batches of whole blocks bound the workspace (28 bytes per input byte); blocks are independent
+    const size_t max_sub = std::max<size_t>(block_size, (size_t)256 << 20);
+    const size_t blocks_per_sub = std::max<size_t>(1, max_sub / block_size);
+    for (size_t off = 0; off < total_len;) {
+        const size_t sub = std::min(total_len - off, blocks_per_sub * block_size);
+        const size_t nb = (sub + block_size - 1) / block_size, b0 = off / block_size;
+        if ((rc = grow(&d.d_in, &d.in_cap, sub))) return rc;
+        if ((rc = grow(&d.d_out, &d.out_cap, sub))) return rc;
+        if ((rc = grow(&d.d_ws, &d.ws_cap, grid_geom(sub, std::min(block_size, sub), true).bytes))) return rc;
+        if ((rc = grow(&d.d_aux, &d.aux_cap, nb * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(d.d_in, in + off, sub, hipMemcpyHostToDevice, d.stream));
+        rc = bwtgpu_forward_origin_batch_device(device, (const uint8_t*)d.d_in, sub, block_size, (uint8_t*)d.d_out,
+                                                (uint32_t*)d.d_aux, d.d_ws, d.ws_cap, d.stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(rows + b0, d.d_aux, nb * 4, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipMemcpyAsync(out + off, d.d_out, sub, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        off += sub;
+    }
+    return BWTGPU_OK;
 }
 
 int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t delimiter,

@@ -1,6 +1,7 @@
 // bzip2_format.cpp -- see bzip2_format.hpp.
 #include "bzip2_format.hpp"
 
+#include <algorithm>
 #include <cstdint>
 #include <iostream>
 
@@ -42,6 +43,65 @@ bool Bzip2BWTProcessor::read_bzip2_block(std::ifstream& in, size_t block_size, i
         return false;
     }
     return true;
+}
+
+bool Bzip2BWTProcessor::forward_bwt(const unsigned char* data, size_t size, std::vector<unsigned char>& bwt_output,
+                                    int& origPtr) {
+    bwt_output.resize(size);
+    origPtr = 0;
+    if (size == 0) return true;
+    uint32_t row = 0;
+    if (bwtgpu_forward_origin_batch(0, data, size, size, bwt_output.data(), &row) != BWTGPU_OK) {
+        std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+        return false;
+    }
+    origPtr = (int)row;
+    return true;
+}
+
+int Bzip2BWTProcessor::process_file_forward(const char* input_file, const char* output_file, size_t block_size) {
+    std::ifstream in(input_file, std::ios::binary);
+    if (!in.is_open()) {
+        std::cerr << "Error: Cannot open input file: " << input_file << std::endl;
+        return 1;
+    }
+    std::ofstream out(output_file, std::ios::binary);
+    if (!out.is_open()) {
+        std::cerr << "Error: Cannot open output file: " << output_file << std::endl;
+        return 1;
+    }
+    if (block_size == 0) return 0;  // nothing is read per block then
+    if (block_size > ((size_t)1 << 24)) {  // the container stores the row in three bytes
+        std::cerr << "Error: Block size " << block_size << " exceeds maximum " << ((size_t)1 << 24) << std::endl;
+        return 1;
+    }
+    // whole blocks in batches of bounded size, each batch one call
+    const size_t kBatchBytes = (size_t)256 << 20;
+    size_t per_batch = std::max<size_t>(1, kBatchBytes / block_size) * block_size;
+    in.seekg(0, std::ios::end);
+    const std::streamoff file_bytes = in.tellg();  // (-1: not seekable; the full batch buffer then)
+    in.seekg(0, std::ios::beg);
+    if (file_bytes >= 0 && (size_t)file_bytes < per_batch) per_batch = std::max<size_t>(1, (size_t)file_bytes);
+    std::vector<unsigned char> text(per_batch), last, block;
+    std::vector<uint32_t> rows;
+    while (in.good()) {
+        in.read(reinterpret_cast<char*>(text.data()), (std::streamsize)per_batch);
+        const size_t got = (size_t)in.gcount();
+        if (got == 0) break;
+        const size_t nb = (got + block_size - 1) / block_size;
+        last.resize(got);
+        rows.resize(nb);
+        if (bwtgpu_forward_origin_batch(0, text.data(), got, block_size, last.data(), rows.data()) != BWTGPU_OK) {
+            std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+            return 1;
+        }
+        for (size_t b = 0; b < nb; ++b) {
+            const size_t lo = b * block_size, hi = std::min(got, lo + block_size);
+            block.assign(last.begin() + (long)lo, last.begin() + (long)hi);
+            if (!write_bzip2_block(out, (int)rows[b], block)) return 1;
+        }
+    }
+    return 0;
 }
 
 std::string Bzip2BWTProcessor::inverse_bwt(const std::vector<unsigned char>& bwt_str, int origPtr) {

@@ -147,6 +147,23 @@ int bwtgpu_inverse_origin_batch_device(int device, const uint8_t* d_in, size_t t
 int bwtgpu_inverse_origin_batch(int device, const uint8_t* in, size_t total_len, size_t block_size,
                                 const uint32_t* orig_ptr, uint8_t* out);
 
+/* ---- forward of origin-pointer blocks: what the comparison tool's process_block produces (reference
+ *      util/bzip2_bwt_utils.cpp:104-136: the block's rotations sorted -- there by BZ2_blockSort, bzip2
+ *      1.0.x --, extract_bwt_output :77-96: the byte before each sorted rotation, the block's last byte
+ *      for rotation 0, and origPtr = the row of rotation 0).  Block i of `in` (block_size bytes, the last
+ *      one possibly shorter) gives its last column at out + i*block_size and its row in rows[i].
+ *      Rotations are ordered as unsigned bytes; equal rotations (a block that is a shorter string
+ *      repeated) by position, so rows[i] is the first of the tied rows -- any choice among them inverts
+ *      to the same text.  The whole batch is sorted by all compute units together (prefix doubling on
+ *      ranks read modulo the block length); the call drives the rounds from the host and blocks until
+ *      the last one is enqueued.  At most 2^31 bytes per batch; 28 bytes of workspace per input byte. */
+size_t bwtgpu_forward_origin_workspace_bytes(int device, size_t total_len, size_t block_size);
+int bwtgpu_forward_origin_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
+                                       uint8_t* d_out, uint32_t* d_rows, void* d_workspace, size_t workspace_bytes,
+                                       void* stream);
+int bwtgpu_forward_origin_batch(int device, const uint8_t* in, size_t total_len, size_t block_size, uint8_t* out,
+                                uint32_t* rows);
+
 /* ---- slab pipeline: replaces the reader -> BlockingQueue -> workers -> ReorderBuffer ->
  *      writer threads of reference src/bwt.cpp:183-233 (and the serial read/transform/write
  *      loop of src/inverse_bwt.cpp:85-95).  The caller fills a pinned input slab with whole

@@ -2,7 +2,8 @@
 // through the C++ mirror of Bzip2BWTProcessor: containers are made here on the CPU from the textbook
 // definition (sort the rotations of every block, last column, row of rotation 0 -- what
 // BZ2_blockSort computes), written with write_bzip2_block, inverted on the GPU with
-// process_file_inverse / inverse_bwt and compared with the original bytes.
+// process_file_inverse / inverse_bwt and compared with the original bytes; the GPU's own forward half
+// (forward_bwt / process_file_forward) is checked against the same definition.
 #include <algorithm>
 #include <cstdio>
 #include <fstream>
@@ -97,6 +98,29 @@ int main(int argc, char** argv) {
     std::vector<unsigned char> periodic(6300);
     for (size_t i = 0; i < periodic.size(); ++i) periodic[i] = (unsigned char)('a' + i % 7);
     for (size_t bs : {(size_t)1000, (size_t)2100, (size_t)4200, (size_t)6300}) round_trip("period-7", periodic, bs);
+    {   // the forward half on the GPU: same last column and row as the definition, and file to file and back
+        std::vector<unsigned char> last, want;
+        const std::string words[] = {"banana", "abababab", "z", "mississippi", "aaaaaaaaaaaaaaaa"};
+        for (const std::string& w : words) {
+            const std::vector<unsigned char> s(w.begin(), w.end());
+            const int want_orig = rotation_transform(s, want);
+            int orig = -1;
+            check(Bzip2BWTProcessor::forward_bwt(s.data(), s.size(), last, orig) && last == want && orig == want_orig,
+                  "forward_bwt(\"" + w + "\")");
+        }
+        const std::string src = "build/tmp/origin_src.bin", fwd = "build/tmp/origin_fwd.bz2bwt", back = "build/tmp/origin_back.bin";
+        for (size_t bs : {(size_t)1, (size_t)7, (size_t)2000, (size_t)16384, (size_t)65536}) {
+            std::ofstream(src, std::ios::binary).write(reinterpret_cast<const char*>(text.data()), (std::streamsize)text.size());
+            const int rc1 = Bzip2BWTProcessor::process_file_forward(src.c_str(), fwd.c_str(), bs);
+            const size_t nb = (text.size() + bs - 1) / bs;
+            const bool sized = get_file_size(fwd) == text.size() + 4 * nb;
+            const int rc2 = Bzip2BWTProcessor::process_file_inverse(fwd.c_str(), back.c_str(), bs);
+            check(rc1 == 0 && rc2 == 0 && sized && slurp(back) == text, "process_file_forward / _inverse @ " + format_size(bs));
+        }
+        std::remove(src.c_str());
+        std::remove(fwd.c_str());
+        std::remove(back.c_str());
+    }
     {   // a malformed container: reading stops at the bad block, what came before is kept
         const std::string fwd = "build/tmp/origin_bad.bz2bwt", back = "build/tmp/origin_bad.out";
         std::ofstream out(fwd, std::ios::binary);

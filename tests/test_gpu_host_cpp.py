@@ -297,3 +297,18 @@ def test_performance_tool(tmp_path):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):  # kept so that a captured log can be committed as the parser fixture
         open(os.path.join(out, "performance_two_files.log"), "w").write(r.stdout)
+
+
+def test_compare_tool():
+    """build/compare_bwt_performance (the shape of the reference's tests/compare_bwt_performance.cpp: five
+    trials at 64 / 128 / 256 KiB, forward, inverse, round trip): nine SUMMARY lines in the reference's
+    grammar (util/performance_comparison.cpp:297-312), every trial's two round trips verified by the tool."""
+    r = run([os.path.join(BUILD, "compare_bwt_performance"), os.path.join(CORPUS, "alice29.txt")])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l.split("|") for l in r.stdout.splitlines() if l.startswith("SUMMARY|")]
+    assert [l[2] for l in lines] == ["forward", "inverse", "roundtrip"] * 3
+    for l in lines:
+        assert len(l) == 8 and l[1] == "alice29.txt" and l[6] in ("your_bwt", "bzip2")
+        assert float(l[3]) > 0 and float(l[4]) > 0 and float(l[5]) > 0 and float(l[7]) >= 0
+    assert r.stdout.count("(successful: 5)") == 3
+    assert run([os.path.join(BUILD, "compare_bwt_performance"), "/nonexistent"]).returncode == 1

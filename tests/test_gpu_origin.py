@@ -75,6 +75,40 @@ def test_inverse_matches_oracle_and_text(orc, name, data, bs):
     assert got == want
 
 
+@pytest.mark.parametrize("name,data,bs", CASES, ids=[c[0] for c in CASES])
+def test_forward_matches_oracle(orc, name, data, bs):
+    """Rotation sort on the GPU against the oracle's (last column and origin row of every block), and back
+    through the GPU inverse."""
+    want_last, want_rows = make_batch(orc, data, bs)
+    last, rows = api.forward_origin_batch(data, bs)
+    assert last == want_last
+    assert list(rows) == list(want_rows)
+    assert api.inverse_origin_batch(last, bs, rows) == data
+
+
+def test_forward_many_blocks_and_long_equal_rotations(orc):
+    """More blocks than one workgroup's list holds still tied when the depth reaches the block length (every
+    rotation of a block of one byte value equals every other), and many short blocks."""
+    for data, bs in ((b"z" * 300000, 100000), (bytes(65 + i % 3 for i in range(3 * 40000)), 3 * 20000),
+                     (synth.generate("acgt", 11, 0, 300 * 2000 + 55).tobytes(), 2000),
+                     (synth.generate("random255", 5, 0, 1 << 20).tobytes(), 1 << 18)):
+        want_last, want_rows = make_batch(orc, data, bs)
+        last, rows = api.forward_origin_batch(data, bs)
+        assert last == want_last and list(rows) == list(want_rows), (len(data), bs)
+
+
+def test_forward_container_round_trip(orc, tmp_path):
+    """Text -> container (0xFF, row, last column per block) -> text, the container parsed as the reference's
+    reader does."""
+    data = text_bytes(200000)
+    last, rows = api.forward_origin_batch(data, 65536)
+    raw = api.build_origin_container(last, 65536, rows)
+    assert len(raw) == len(data) + 4 * len(rows)
+    cols, got_rows = api.parse_origin_container(raw, 65536)
+    assert cols.tobytes() == last and list(got_rows) == list(rows)
+    assert api.inverse_origin_batch(cols, 65536, got_rows) == data
+
+
 def test_many_blocks(orc):
     data = synth.generate("acgt", 11, 0, 300 * 2000 + 55).tobytes()
     last, rows = make_batch(orc, data, 2000)
