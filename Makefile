@@ -17,12 +17,13 @@ LDFLAGS  := -Lbwt_amd -lbwtgpu -Wl,-rpath,'$$ORIGIN/../bwt_amd' -pthread
 MAIN_EXECS := $(BUILD)/bwt $(BUILD)/inverse_bwt
 TEST_EXECS := $(BUILD)/test_small $(BUILD)/test_medium $(BUILD)/test_bzip2_format
 PERF_EXECS := $(BUILD)/performance $(BUILD)/compare_bwt_performance
+ORIGIN_EXECS := $(BUILD)/bzip2_bwt_extractor $(BUILD)/bzip2_inverse_bwt_extractor
 TEST_LIB_OBJS := $(BUILD)/src_test/bwt.o $(BUILD)/src_test/inverse_bwt.o $(BUILD)/src_test/file_processor.o \
                  $(BUILD)/src_test/bzip2_format.o
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/bwtgpu.h
 
 .PHONY: all lib test performance clean rebuild
-all: lib $(MAIN_EXECS) $(TEST_EXECS) $(PERF_EXECS)
+all: lib $(MAIN_EXECS) $(TEST_EXECS) $(PERF_EXECS) $(ORIGIN_EXECS)
 lib: $(LIB)
 
 $(LIB): $(CSRC)/bwtgpu.hip $(wildcard $(CSRC)/*.hpp) include/bwtgpu.h
@@ -36,7 +37,7 @@ $(BUILD)/inverse_bwt: $(BUILD)/src/inverse_bwt.o $(BUILD)/src/file_processor.o |
 	@echo "Building $@"
 	@$(CXX) $(CXXFLAGS) $^ -o $@ $(LDFLAGS)
 
-$(TEST_EXECS) $(PERF_EXECS): $(BUILD)/%: $(TESTS)/%.cpp $(TEST_LIB_OBJS) $(HOST_HDRS) | $(LIB)
+$(TEST_EXECS) $(PERF_EXECS) $(ORIGIN_EXECS): $(BUILD)/%: $(TESTS)/%.cpp $(TEST_LIB_OBJS) $(HOST_HDRS) $(wildcard $(TESTS)/*.hpp) | $(LIB)
 	@echo "Building $@"
 	@$(CXX) $(CXXFLAGS) -DBUILD_TESTS $(INCLUDES) $< $(TEST_LIB_OBJS) -o $@ $(LDFLAGS)
 

@@ -41,6 +41,8 @@ SYMBOLS = [
     "bwtgpu_pipeline_create", "bwtgpu_pipeline_input", "bwtgpu_pipeline_input_capacity",
     "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
     "bwtgpu_pipeline_upload_presence", "bwtgpu_forward_batch_static", "bwtgpu_time_resident",
+    "bwtgpu_pipeline_reserve", "bwtgpu_pipeline_stage", "bwtgpu_pipeline_stage_wait", "bwtgpu_pipeline_presence",
+    "bwtgpu_pipeline_submit_resident",
     "bwtgpu_inverse_origin_workspace_bytes", "bwtgpu_inverse_origin_batch_device", "bwtgpu_inverse_origin_batch",
     "bwtgpu_forward_origin_workspace_bytes", "bwtgpu_forward_origin_batch_device", "bwtgpu_forward_origin_batch",
 ]
@@ -114,6 +116,11 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_pipeline_collect.restype = _i
     L.bwtgpu_pipeline_upload_presence.argtypes = [_vp, _i, _sz, ctypes.POINTER(ctypes.c_uint32)]
     L.bwtgpu_pipeline_upload_presence.restype = _i
+    L.bwtgpu_pipeline_reserve.argtypes, L.bwtgpu_pipeline_reserve.restype = [_vp, _sz], _i
+    L.bwtgpu_pipeline_stage.argtypes, L.bwtgpu_pipeline_stage.restype = [_vp, _i, _sz, _sz], _i
+    L.bwtgpu_pipeline_stage_wait.argtypes, L.bwtgpu_pipeline_stage_wait.restype = [_vp, _i], _i
+    L.bwtgpu_pipeline_presence.argtypes, L.bwtgpu_pipeline_presence.restype = [_vp, ctypes.POINTER(ctypes.c_uint32)], _i
+    L.bwtgpu_pipeline_submit_resident.argtypes, L.bwtgpu_pipeline_submit_resident.restype = [_vp, _i, _sz, ctypes.c_uint8], _i
     L.bwtgpu_pipeline_destroy.argtypes, L.bwtgpu_pipeline_destroy.restype = [_vp], None
     _lib = L
     return L

@@ -74,16 +74,19 @@ struct Device {
     hipStream_t stream = nullptr;
     uint8_t* static_ws = nullptr;  // this device's copy of `scratch` (nullptr: the lookup failed, see static_ws_error)
     hipError_t static_ws_error = hipSuccess;
-    // Pinned host word the device writes at the end of an inverse batch that went through the in-LDS inverse
+    // Pinned host words the device writes at the end of an inverse batch that went through the in-LDS inverse
     // first: the blocks that kernel did not finish.  0 = the table kernels found nothing to do, and the
     // next such batch launches them as small striding grids (a guess about the data: either way of
-    // launching gives the same bytes).
+    // launching gives the same bytes).  kInvHints words, one per stream (by a hash of its handle), so that
+    // two pipelines with different data on one device do not overturn each other's guess.
     uint32_t* inv_left = nullptr;
-    uint32_t* inv_left_dev = nullptr;  // the same word as the device addresses it
+    uint32_t* inv_left_dev = nullptr;  // the same words as the device addresses them
     bool ready = false;
     std::mutex mu;          // one host-pointer call at a time per device
     std::mutex init_mu;     // guards first-use binding
 };
+
+constexpr int kInvHints = 16;  // (64 bytes of pinned memory)
 
 std::mutex g_mu;
 std::vector<Device*> g_dev;
@@ -495,7 +498,7 @@ int ensure_device(int device) {
     if (d->static_ws_error != hipSuccess) (void)hipGetLastError();  // the failure stays with bwtgpu_forward_batch_static, which reports it
     if (hipHostMalloc((void**)&d->inv_left, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess &&
         hipHostGetDevicePointer((void**)&d->inv_left_dev, d->inv_left, 0) == hipSuccess) {
-        *d->inv_left = 0xFFFFFFFFu;
+        for (int i = 0; i < kInvHints; ++i) d->inv_left[i] = 0xFFFFFFFFu;
     } else {
         if (d->inv_left) (void)hipHostFree(d->inv_left);
         d->inv_left = d->inv_left_dev = nullptr;
@@ -794,6 +797,8 @@ struct PipeSlot {
     hipEvent_t done = nullptr;
     size_t in_bytes = 0;
     size_t resident = 0;  // bytes of h_in already uploaded by bwtgpu_pipeline_upload_presence
+    hipEvent_t staged = nullptr;  // bwtgpu_pipeline_stage: the upload out of h_in has finished
+    bool staging = false;
     bool busy = false;
 };
 
@@ -807,6 +812,12 @@ struct bwtgpu_pipeline {
     size_t in_cap = 0, out_cap = 0, ws_bytes = 0;
     uint8_t delimiter = 0;
     std::vector<PipeSlot> slots;
+    // bwtgpu_pipeline_reserve: uploaded slabs kept on the device (slab k at d_resident + k * in_cap) and the
+    // byte values seen in them so far
+    uint8_t* d_resident = nullptr;
+    size_t resident_slabs = 0;
+    std::vector<size_t> resident_bytes;
+    uint32_t* d_presence = nullptr;
 };
 
 namespace {
@@ -824,8 +835,11 @@ void pipeline_free(bwtgpu_pipeline* p) {
         if (s.d_lens) (void)hipFree(s.d_lens);
         if (s.d_ws) (void)hipFree(s.d_ws);
         if (s.done) (void)hipEventDestroy(s.done);
+        if (s.staged) (void)hipEventDestroy(s.staged);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
+    if (p->d_resident) (void)hipFree(p->d_resident);
+    if (p->d_presence) (void)hipFree(p->d_presence);
     delete p;
 }
 
@@ -843,6 +857,7 @@ int pipeline_alloc(bwtgpu_pipeline* p, int depth) {
         s.ws_cap = p->ws_bytes;
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
     }
     return BWTGPU_OK;
 }
@@ -1065,8 +1080,9 @@ int inverse_launch(int device, const uint8_t* d_in, size_t total, size_t block_s
     {
         if (g.pack_wgs && !d_orig_ptr) {
             a.packed_first = 1;
-            a.left_hint = d.inv_left_dev;
-            sparse = d.inv_left && __atomic_load_n(d.inv_left, __ATOMIC_RELAXED) == 0u;
+            const size_t hint = (((uintptr_t)s >> 4) ^ ((uintptr_t)s >> 12)) % (size_t)kInvHints;
+            a.left_hint = d.inv_left_dev ? d.inv_left_dev + hint : nullptr;
+            sparse = d.inv_left && __atomic_load_n(d.inv_left + hint, __ATOMIC_RELAXED) == 0u;
             hipLaunchKernelGGL(bwt_inverse_packed_classify_kernel,
                                dim3((uint32_t)((g.nblocks + kPackClassifyThreads / kWave - 1) / (kPackClassifyThreads / kWave))),
                                dim3(kPackClassifyThreads), 0, s, a);
@@ -1534,15 +1550,18 @@ uint8_t* bwtgpu_pipeline_input(bwtgpu_pipeline* p, int slot) {
 
 size_t bwtgpu_pipeline_input_capacity(const bwtgpu_pipeline* p) { return p ? p->in_cap : 0; }
 
-int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter) {
-    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+namespace {
+// The transform of `bytes` bytes into slot s's output: from d_src if given (already on the device), else from
+// the slot's own input buffer, uploaded first unless bwtgpu_pipeline_upload_presence has done that.
+int pipeline_run(bwtgpu_pipeline* p, int slot, const uint8_t* d_src, size_t bytes, uint8_t delimiter) {
     PipeSlot& s = p->slots[(size_t)slot];
     if (s.busy) return fail(BWTGPU_ERR_INVALID, "slot %d submitted again before it was collected", slot);
     if (bytes > p->in_cap) return fail(BWTGPU_ERR_INVALID, "%zu bytes exceed the slab capacity %zu", bytes, p->in_cap);
     HIP_TRY(hipSetDevice(p->device));
     s.in_bytes = bytes;
     p->delimiter = delimiter;
-    const bool uploaded = bytes && s.resident == bytes;
+    const bool uploaded = d_src || (bytes && s.resident == bytes);
+    if (!d_src) d_src = s.d_in;
     s.resident = 0;
     if (bytes) {
         // The slot's workspace was sized for every shape a slab can take; should a batch still ask
@@ -1560,14 +1579,14 @@ int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t d
         if (!uploaded) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
         int rc;
         if (p->direction == BWTGPU_FORWARD) {
-            rc = bwtgpu_forward_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_ws,
+            rc = bwtgpu_forward_batch_device(p->device, d_src, bytes, p->block_size, delimiter, s.d_out, s.d_ws,
                                              s.ws_cap, s.stream);
             if (rc) return rc;
             const size_t nb = (bytes + p->block_size - 1) / p->block_size;
             HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, bytes + nb, hipMemcpyDeviceToHost, s.stream));
             HIP_TRY(hipMemcpyAsync(s.h_lens, s.d_ws, 8, hipMemcpyDeviceToHost, s.stream));
         } else {
-            rc = bwtgpu_inverse_batch_device(p->device, s.d_in, bytes, p->block_size, delimiter, s.d_out, s.d_lens,
+            rc = bwtgpu_inverse_batch_device(p->device, d_src, bytes, p->block_size, delimiter, s.d_out, s.d_lens,
                                              s.d_ws, s.ws_cap, s.stream);
             if (rc) return rc;
             const size_t nb = (bytes + p->block_size) / (p->block_size + 1);
@@ -1578,6 +1597,80 @@ int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t d
     HIP_TRY(hipEventRecord(s.done, s.stream));
     s.busy = true;
     return BWTGPU_OK;
+}
+}  // namespace
+
+int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    return pipeline_run(p, slot, nullptr, bytes, delimiter);
+}
+
+int bwtgpu_pipeline_reserve(bwtgpu_pipeline* p, size_t nslabs) {
+    if (!p || p->direction != BWTGPU_FORWARD || nslabs == 0) return fail(BWTGPU_ERR_INVALID, "resident slabs: a forward pipeline and at least one slab");
+    HIP_TRY(hipSetDevice(p->device));
+    for (PipeSlot& s : p->slots) HIP_TRY(hipStreamSynchronize(s.stream));  // nothing may still read the old slabs
+    if (nslabs > p->resident_slabs) {
+        if (p->d_resident) HIP_TRY(hipFree(p->d_resident));
+        p->d_resident = nullptr;
+        p->resident_slabs = 0;
+        if (hipMalloc((void**)&p->d_resident, nslabs * p->in_cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(BWTGPU_ERR_HIP, "no device memory for %zu resident slabs of %zu bytes", nslabs, p->in_cap);
+        }
+        p->resident_slabs = nslabs;
+    }
+    if (!p->d_presence) HIP_TRY(hipMalloc((void**)&p->d_presence, 32));
+    HIP_TRY(hipMemsetAsync(p->d_presence, 0, 32, p->slots[0].stream));
+    HIP_TRY(hipStreamSynchronize(p->slots[0].stream));
+    p->resident_bytes.assign(p->resident_slabs, 0);
+    for (PipeSlot& s : p->slots) s.staging = false;
+    return BWTGPU_OK;
+}
+
+int bwtgpu_pipeline_stage(bwtgpu_pipeline* p, int slot, size_t k, size_t bytes) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    if (k >= p->resident_slabs) return fail(BWTGPU_ERR_INVALID, "resident slab %zu of %zu reserved", k, p->resident_slabs);
+    PipeSlot& s = p->slots[(size_t)slot];
+    if (s.busy) return fail(BWTGPU_ERR_INVALID, "slot %d is in flight", slot);
+    if (bytes > p->in_cap) return fail(BWTGPU_ERR_INVALID, "%zu bytes exceed the slab capacity %zu", bytes, p->in_cap);
+    HIP_TRY(hipSetDevice(p->device));
+    p->resident_bytes[k] = bytes;
+    if (bytes) {
+        uint8_t* dst = p->d_resident + k * p->in_cap;
+        HIP_TRY(hipMemcpyAsync(dst, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipEventRecord(s.staged, s.stream));
+        s.staging = true;
+        const int rc = bwtgpu_presence_device(p->device, dst, bytes, p->d_presence, s.stream);  // (ORs into the mask)
+        if (rc) return rc;
+    }
+    return BWTGPU_OK;
+}
+
+int bwtgpu_pipeline_stage_wait(bwtgpu_pipeline* p, int slot) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    PipeSlot& s = p->slots[(size_t)slot];
+    if (!s.staging) return BWTGPU_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(s.staged));
+    s.staging = false;
+    return BWTGPU_OK;
+}
+
+int bwtgpu_pipeline_presence(bwtgpu_pipeline* p, uint32_t presence_out[8]) {
+    if (!p || !presence_out || !p->d_presence) return fail(BWTGPU_ERR_INVALID, "no resident slabs reserved");
+    HIP_TRY(hipSetDevice(p->device));
+    for (PipeSlot& s : p->slots) {
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        s.staging = false;
+    }
+    HIP_TRY(hipMemcpy(presence_out, p->d_presence, 32, hipMemcpyDeviceToHost));
+    return BWTGPU_OK;
+}
+
+int bwtgpu_pipeline_submit_resident(bwtgpu_pipeline* p, int slot, size_t k, uint8_t delimiter) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    if (k >= p->resident_slabs) return fail(BWTGPU_ERR_INVALID, "resident slab %zu of %zu reserved", k, p->resident_slabs);
+    return pipeline_run(p, slot, p->d_resident + k * p->in_cap, p->resident_bytes[k], delimiter);
 }
 
 int bwtgpu_pipeline_upload_presence(bwtgpu_pipeline* p, int slot, size_t bytes, uint32_t presence_out[8]) {

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -140,6 +141,28 @@ int bwt_forward_process_file(const char* input_file, const char* output_file, si
     bwt_host::trace_point("start");
     const int fast = forward_single_slab(input_file, output_file, block_size);
     if (fast >= 0) return fast;
+    if (block_size != 0 && block_size <= BWTGPU_MAX_BLOCK_SIZE && readable(input_file)) {
+        // a regular file of several slabs that fits the devices: read and uploaded once (the delimiter is
+        // found on the uploaded bytes), see run_forward_resident
+        FileProcessor reader(input_file, "", block_size);
+        std::unique_ptr<FileProcessor> writer;
+        const int rc = !reader.is_open() ? -1 : bwt_host::run_forward_resident(reader, block_size, [&](char delimiter) -> FileProcessor* {
+            writer.reset(new FileProcessor(input_file, output_file, block_size));
+            if (!writer->is_open()) return nullptr;
+            if (!writer->write_bytes(&delimiter, 1)) {
+                std::cerr << "Error: short write to the output file" << std::endl;
+                return nullptr;
+            }
+            const size_t n = reader.input_size();
+            writer->reserve_output(1 + n + (n + block_size - 1) / block_size);
+            return writer.get();
+        });
+        if (writer) {
+            writer->close();
+            bwt_host::trace_point("closed");
+        }
+        if (rc >= 0) return rc;
+    }
     const int delimiter_byte = find_unique_char(input_file);
     bwt_host::trace_point("delimiter found");
     if (delimiter_byte == -1) {

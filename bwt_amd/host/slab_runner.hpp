@@ -381,6 +381,132 @@ inline int run_slabs_threaded(FileProcessor& processor, int direction, size_t bl
     return failed ? 1 : 0;
 }
 
+// Most bytes of one file kept on the devices between the upload and the transform: BWT_RESIDENT_MIB per
+// GPU, default 16384 (of 288 GB; longer files take the two-pass route).  0 turns the route off.
+inline size_t resident_max_bytes() {
+    static const size_t n = [] {
+        const char* e = std::getenv("BWT_RESIDENT_MIB");
+        const long v = e ? std::atol(e) : -1;
+        return (size_t)(v >= 0 && v <= 262144 ? v : 16384) << 20;
+    }();
+    return n;
+}
+
+// Forward of a regular file in ONE pass over it: every slab is read and uploaded once, to the GPU that will
+// transform it (slab k: GPU k % G), which looks at its byte values on the way; once all are up the masks
+// give the delimiter (the reference's first pass over the file, src/bwt.cpp:19-47, reads it a second
+// time for this), the header is written and the resident slabs are transformed, collected in file order
+// and written.  `open_output(delimiter)` is called once the delimiter is known and returns the processor
+// to write to (nullptr: failed, message printed).  Returns -1 if the route does not apply (the caller
+// then takes the two-pass route), else the exit code.
+template <typename OpenOutput>
+inline int run_forward_resident(FileProcessor& reader, size_t block_size, OpenOutput open_output) {
+    const size_t size = reader.input_size();
+    if (!reader.input_is_regular() || size == 0) return -1;
+    const int ndev = device_budget();
+    if (ndev <= 0) return -1;
+    if (size > resident_max_bytes() * (size_t)ndev) return -1;
+    const int depth = 2;
+    const size_t slab_blocks = slab_blocks_for(block_size, size);
+    const size_t slab_bytes = slab_blocks * block_size;
+    const size_t nslabs = (size + slab_bytes - 1) / slab_bytes;
+    const size_t per_dev = (nslabs + (size_t)ndev - 1) / (size_t)ndev;
+    std::vector<PipelineCache::Lease> leases((size_t)ndev);
+    std::vector<bwtgpu_pipeline*> pipes((size_t)ndev, nullptr);
+    int rc = 0;
+    auto give_back = [&](bool reusable) {
+        for (size_t d = 0; d < pipes.size(); ++d) {
+            if (!pipes[d]) continue;
+            if (reusable) PipelineCache::instance().release(leases[d], (int)d, BWTGPU_FORWARD, block_size, depth);
+            else bwtgpu_pipeline_destroy(pipes[d]);
+        }
+    };
+    auto gpu_error = [&] {
+        std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
+        give_back(false);
+        return 1;
+    };
+    const int used = (int)std::min<size_t>((size_t)ndev, nslabs);
+    for (int d = 0; d < used; ++d) {
+        leases[(size_t)d] = PipelineCache::instance().acquire(d, BWTGPU_FORWARD, block_size, slab_blocks, depth);
+        pipes[(size_t)d] = leases[(size_t)d].p;
+        if (!pipes[(size_t)d]) {  // (e.g. no memory for another pipeline): let the other route try
+            give_back(true);
+            return -1;
+        }
+        if (bwtgpu_pipeline_reserve(pipes[(size_t)d], per_dev) != BWTGPU_OK) {
+            give_back(true);
+            return -1;
+        }
+    }
+    trace_point("pipelines ready");
+    // pass 1: read, upload, look
+    size_t total = 0, k = 0;
+    for (; k < nslabs; ++k) {
+        const int dev = (int)(k % (size_t)ndev), slot = (int)((k / (size_t)ndev) % (size_t)depth);
+        bwtgpu_pipeline* p = pipes[(size_t)dev];
+        if (bwtgpu_pipeline_stage_wait(p, slot) != BWTGPU_OK) return gpu_error();
+        const size_t got = reader.read_bytes(reinterpret_cast<char*>(bwtgpu_pipeline_input(p, slot)), slab_bytes);
+        if (got == 0) break;
+        if (bwtgpu_pipeline_stage(p, slot, k / (size_t)ndev, got) != BWTGPU_OK) return gpu_error();
+        total += got;
+        if (got < slab_bytes) {
+            ++k;
+            break;
+        }
+    }
+    char extra;
+    if (total != size || reader.read_char(extra)) {  // the file changed under us
+        give_back(true);
+        return -1;
+    }
+    const size_t staged = k;
+    uint32_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int d = 0; d < used; ++d) {
+        uint32_t mask[8];
+        if (bwtgpu_pipeline_presence(pipes[(size_t)d], mask) != BWTGPU_OK) return gpu_error();
+        for (int i = 0; i < 8; ++i) seen[i] |= mask[i];
+    }
+    trace_point("file resident, delimiter known");
+    const int delimiter_byte = bwtgpu_lowest_clear_bit(seen);
+    if (delimiter_byte < 0) {
+        std::cerr << "Error: Cannot find a unique delimiter (all 256 byte values appear in file)" << std::endl;
+        give_back(true);
+        return 1;
+    }
+    FileProcessor* writer = open_output(static_cast<char>(delimiter_byte));
+    if (!writer) {
+        give_back(true);
+        return 1;
+    }
+    // pass 2: transform the resident slabs; up to `depth` per GPU in flight, collected and written in file order
+    size_t submitted = 0, collected = 0;
+    while (collected < staged && !rc) {
+        while (submitted < staged && submitted - collected < (size_t)ndev * (size_t)depth) {
+            const int dev = (int)(submitted % (size_t)ndev), slot = (int)((submitted / (size_t)ndev) % (size_t)depth);
+            if (bwtgpu_pipeline_submit_resident(pipes[(size_t)dev], slot, submitted / (size_t)ndev, (uint8_t)delimiter_byte) != BWTGPU_OK)
+                return gpu_error();
+            ++submitted;
+        }
+        const int dev = (int)(collected % (size_t)ndev), slot = (int)((collected / (size_t)ndev) % (size_t)depth);
+        const uint8_t* out = nullptr;
+        size_t n = 0;
+        if (bwtgpu_pipeline_collect(pipes[(size_t)dev], slot, &out, &n) != BWTGPU_OK) return gpu_error();
+        if (!writer->write_bytes(reinterpret_cast<const char*>(out), n)) {
+            std::cerr << "Error: short write to the output file" << std::endl;
+            rc = 1;
+        }
+        ++collected;
+    }
+    if (rc) {  // slots may still be in flight: do not hand such a pipeline to the next caller
+        give_back(false);
+        return rc;
+    }
+    trace_point("slabs done");
+    give_back(true);
+    return 0;
+}
+
 inline int run_slabs(FileProcessor& processor, int direction, size_t block_size, unsigned char delimiter,
                      size_t remaining_bytes) {
     const size_t unit = direction == BWTGPU_FORWARD ? block_size : block_size + 1;

@@ -188,6 +188,24 @@ int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t d
  * a file that fits one slab is read and uploaded once for both the delimiter search
  * (reference src/bwt.cpp:19-47 reads the file a first time for it) and the transform. */
 int bwtgpu_pipeline_upload_presence(bwtgpu_pipeline* p, int slot, size_t bytes, uint32_t presence_out[8]);
+/* The same for a file of many slabs (forward pipelines): the delimiter needs the whole file's byte values
+ * before the first block can be transformed, which the reference settles with a first pass over the file
+ * (src/bwt.cpp:19-47).  Here every slab is read and uploaded ONCE and stays on the device until the
+ * delimiter is known; with several GPUs each keeps the slabs it will transform.
+ *   bwtgpu_pipeline_reserve          device memory for `nslabs` slabs of the pipeline's capacity (kept and
+ *                                    reused by later calls that ask for no more); clears the presence mask;
+ *   bwtgpu_pipeline_stage            enqueues the upload of the first `bytes` bytes of the slot's input as
+ *                                    resident slab `k` and folds their byte values into the mask;
+ *   bwtgpu_pipeline_stage_wait       returns once that upload has left the slot's input buffer, which may
+ *                                    then be refilled (no-op for a slot with nothing staged);
+ *   bwtgpu_pipeline_presence         waits for everything staged and returns the mask;
+ *   bwtgpu_pipeline_submit_resident  bwtgpu_pipeline_submit with resident slab `k` as the input; the result
+ *                                    is collected from the slot as usual. */
+int bwtgpu_pipeline_reserve(bwtgpu_pipeline* p, size_t nslabs);
+int bwtgpu_pipeline_stage(bwtgpu_pipeline* p, int slot, size_t k, size_t bytes);
+int bwtgpu_pipeline_stage_wait(bwtgpu_pipeline* p, int slot);
+int bwtgpu_pipeline_presence(bwtgpu_pipeline* p, uint32_t presence_out[8]);
+int bwtgpu_pipeline_submit_resident(bwtgpu_pipeline* p, int slot, size_t k, uint8_t delimiter);
 /* Blocks until the slot is done; *out / *out_bytes describe its pinned result, valid until
  * the slot is submitted again.  Inverse results are already compacted. */
 int bwtgpu_pipeline_collect(bwtgpu_pipeline* p, int slot, const uint8_t** out, size_t* out_bytes);

@@ -123,7 +123,10 @@ def test_two_slab_pipeline_depth(tmp_path):
     # The same file driven by the calling thread alone (multi-slab files normally get a reading thread,
     # one submitting thread per GPU and a writing thread) and with more GPUs asked for than there are:
     # identical bytes both ways.
-    for env in ({"BWT_HOST_SERIAL": "1"}, {"BWT_DEVICES": "8"}):
+    # ... and by the two-pass route (delimiter pass, then reader / submitter / writer threads), which files too
+    # long to stay on the devices and inputs that are not regular files take
+    for env in ({"BWT_HOST_SERIAL": "1"}, {"BWT_DEVICES": "8"}, {"BWT_RESIDENT_MIB": "0"},
+                {"BWT_RESIDENT_MIB": "0", "BWT_HOST_SERIAL": "1"}, {"BWT_SLAB_MIB": "1"}):
         f2, b2 = str(tmp_path / "big2.bwt"), str(tmp_path / "big2.out")
         e = dict(os.environ, **env)
         assert subprocess.run([os.path.join(BUILD, "bwt"), src, f2, "512"], cwd=ROOT, env=e, timeout=600).returncode == 0
@@ -312,3 +315,26 @@ def test_compare_tool():
         assert float(l[3]) > 0 and float(l[4]) > 0 and float(l[5]) > 0 and float(l[7]) >= 0
     assert r.stdout.count("(successful: 5)") == 3
     assert run([os.path.join(BUILD, "compare_bwt_performance"), "/nonexistent"]).returncode == 1
+
+
+def test_origin_extractor_tools(tmp_path):
+    """build/bzip2_bwt_extractor and build/bzip2_inverse_bwt_extractor (the command lines of the reference's
+    tests/bzip2_bwt_extractor.cpp and tests/bzip2_inverse_bwt_extractor.cpp): file -> container -> file."""
+    import oracle
+
+    fwd, inv = os.path.join(BUILD, "bzip2_bwt_extractor"), os.path.join(BUILD, "bzip2_inverse_bwt_extractor")
+    src = os.path.join(CORPUS, "alice29.txt")
+    data = open(src, "rb").read()
+    orc = oracle.origin()
+    for args, bs in (([], 65536), (["20000"], 20000)):
+        f, b = str(tmp_path / "c.bz2bwt"), str(tmp_path / "c.out")
+        assert run([fwd, src, f] + args).returncode == 0
+        raw = open(f, "rb").read()
+        nb = (len(data) + bs - 1) // bs
+        assert len(raw) == len(data) + 4 * nb
+        last, orig = orc.forward(data[:bs])  # the first block against the rotation-sort oracle
+        assert raw[0] == 0xFF and int.from_bytes(raw[1:4], "big") == orig and raw[4:4 + bs] == last
+        assert run([inv, f, b] + args).returncode == 0
+        assert open(b, "rb").read() == data
+    assert run([fwd, src]).returncode == 1
+    assert run([fwd, src, str(tmp_path / "x"), "0"]).returncode == 1
