@@ -726,6 +726,53 @@ def test_slab_pipeline_entry_points(orc):
         L.bwtgpu_pipeline_destroy(inv)
 
 
+def test_resident_slabs_entry_points(orc):
+    """A file of several slabs read and uploaded once: slabs staged into device memory with their byte
+    values folded into one mask, then transformed from there -- against the oracle, slab by slab, with the
+    slots reused and a ragged last slab; and the misuse the calls refuse."""
+    import ctypes
+
+    L = api.lib()
+    rng = np.random.default_rng(23)
+    bs, slab_blocks = 4096, 8
+    cap = bs * slab_blocks
+    data = rng.integers(1, 180, size=5 * cap - 777, dtype=np.uint8)  # five slabs, the last one short
+    delim, want = 0, orc.forward_buffer(data.tobytes(), bs, 4)
+    assert want[0] == delim
+    p = L.bwtgpu_pipeline_create(0, 0, bs, slab_blocks, 2)
+    q = L.bwtgpu_pipeline_create(0, 1, bs, slab_blocks, 1)
+    assert p and q
+    try:
+        mask = (ctypes.c_uint32 * 8)()
+        assert L.bwtgpu_pipeline_presence(p, mask) != 0            # nothing reserved yet
+        assert L.bwtgpu_pipeline_reserve(q, 4) != 0                # an inverse pipeline
+        assert L.bwtgpu_pipeline_reserve(p, 0) != 0
+        for attempt in range(2):                                   # the second time the reservation is reused
+            assert L.bwtgpu_pipeline_reserve(p, 5) == 0
+            assert L.bwtgpu_pipeline_stage(p, 0, 5, 10) != 0       # slab index out of range
+            for k in range(5):
+                slot = k % 2
+                assert L.bwtgpu_pipeline_stage_wait(p, slot) == 0
+                part = data[k * cap:(k + 1) * cap]
+                ctypes.memmove(L.bwtgpu_pipeline_input(p, slot), part.ctypes.data, part.size)
+                assert L.bwtgpu_pipeline_stage(p, slot, k, part.size) == 0
+            assert L.bwtgpu_pipeline_presence(p, mask) == 0
+            assert [v for v in range(256) if (mask[v >> 5] >> (v & 31)) & 1] == sorted(set(data.tolist()))
+            assert L.bwtgpu_lowest_clear_bit(mask) == delim
+            out, n = ctypes.c_void_p(), ctypes.c_size_t()
+            got = b""
+            for k in range(0, 5, 2):                               # two slabs in flight
+                for j in range(k, min(k + 2, 5)):
+                    assert L.bwtgpu_pipeline_submit_resident(p, j % 2, j, delim) == 0
+                for j in range(k, min(k + 2, 5)):
+                    assert L.bwtgpu_pipeline_collect(p, j % 2, ctypes.byref(out), ctypes.byref(n)) == 0
+                    got += ctypes.string_at(out.value, n.value)
+            assert got == want[1:], attempt
+    finally:
+        L.bwtgpu_pipeline_destroy(p)
+        L.bwtgpu_pipeline_destroy(q)
+
+
 def test_concurrent_callers(orc):
     """The per-block functions are called from many worker threads in the reference
     (src/bwt.cpp:143-156): concurrent calls from several host threads give the same bytes."""
