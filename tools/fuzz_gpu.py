@@ -1,6 +1,6 @@
 """Randomised differential test of the GPU path against the CPU oracle (run on a GPU box).
 
-usage: python tools/fuzz_gpu.py [trials] [seed] [big]
+usage: python tools/fuzz_gpu.py [trials] [seed] [big|lds|origin]
 Covers: alphabet sizes incl. powers of two (delimiter above / below / inside the alphabet),
 runs, periodic text, repeated blocks, lengths around the internal size thresholds, batches;
 every trial through one of the forward paths (the batch kernels, the device-wide path, or the
@@ -20,6 +20,8 @@ from bwt_amd import api  # noqa: E402
 orc = oracle.oracle()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 BIG_ONLY = len(sys.argv) > 3 and sys.argv[3] == "big"  # only long blocks and many-block batches
+ORIGIN_ONLY = len(sys.argv) > 3 and sys.argv[3] == "origin"  # the origin-pointer format (sorted rotations), forward and back
+LDS_ONLY = len(sys.argv) > 3 and sys.argv[3] == "lds"  # only the shapes the in-LDS kernels take: blocks of 16-256 KiB, batch path
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 nrng = np.random.default_rng(rng.randrange(1 << 30))
 prng = random.Random(12345)  # forward path per trial, drawn apart so that the inputs do not depend on it
@@ -59,6 +61,59 @@ for t in range(trials):
         n = rng.randrange(100000, 600000)
     elif big < 0.10:  # more blocks than compute units: the 256-thread batch kernel
         n = rng.randrange(280, 600) * rng.choice([4096, 8192, 12000])
+    if ORIGIN_ONLY:
+        n = rng.choice(SIZES) if rng.random() < 0.6 else rng.randrange(1, 120000)
+        data, kind, sigma, base = make(n)
+        bs = rng.choice([n, max(1, n // 2), max(1, n // 3 + 1), 1 + rng.randrange(n), 4096, 7 * 64])
+        origin = oracle.origin()
+        cols, rows = [], []
+        for off in range(0, n, bs):
+            last, row = origin.forward(data[off:off + bs])
+            cols.append(last)
+            rows.append(row)
+        got_last, got_rows = api.forward_origin_batch(data, bs)
+        ok = got_last == b"".join(cols) and list(got_rows) == rows
+        back_ok = ok and api.inverse_origin_batch(got_last, bs, got_rows) == data
+        if not (ok and back_ok):
+            fails += 1
+            print("FAIL", t, "n", n, "bs", bs, kind, "sigma", sigma, "base", base, "fwd", ok, "inv", back_ok, flush=True)
+            if fails > 10:
+                break
+        if t % 100 == 99:
+            print("trial", t + 1, "fails", fails, flush=True)
+        continue
+    if LDS_ONLY:
+        # blocks of 16 KiB .. 256 KiB (at most 64 KiB unless the alphabet is small: the text then fits the LDS both
+        # ways), a handful of them plus a ragged tail, through the batch kernels
+        small = rng.random() < 0.6
+        bs = rng.choice([16384, 16385, 20000, 32768, 49151, 49152, 65535, 65536, 65537, 100000, 131072, 262143, 262144]) if small \
+            else rng.choice([16384, 20000, 32768, 49151, 49152, 60000, 65535, 65536])
+        n = bs * rng.randrange(1, 5) + rng.choice([0, 1, 17, bs // 2, bs - 1])
+        n = min(n, 700000)
+        data, kind, sigma, base = make(n)
+        if small:
+            a = np.frombuffer(data, dtype=np.uint8).astype(np.int64) - base
+            sg = rng.choice([1, 2, 3, 4, 4, 4, 5])
+            data = ((a % sg) * rng.choice([1, 3, 60]) + base // 4).astype(np.uint8).tobytes()
+            sigma = sg
+        os.environ["BWTGPU_FORWARD_PATH"] = "block"
+        os.environ["BWTGPU_INVERSE_PATH"] = prng.choice(["auto", "packed", "general"])
+        try:
+            want = orc.forward_buffer(data, bs, 8)
+        except ValueError:
+            continue
+        delim = want[0]
+        got = api.forward_batch(data, bs, delim)
+        ok = got == want[1:]
+        back_ok = ok and api.inverse_batch(got, bs, delim) == data
+        if not (ok and back_ok):
+            fails += 1
+            print("FAIL", t, "n", n, "bs", bs, kind, "sigma", sigma, "base", base, "delim", delim, "fwd", ok, "inv", back_ok, flush=True)
+            if fails > 10:
+                break
+        if t % 20 == 19:
+            print("trial", t + 1, "fails", fails, flush=True)
+        continue
     data, kind, sigma, base = make(n)
     mode = rng.random()
     path = prng.choice(["auto", "auto", "block", "grid"])
