@@ -20,17 +20,20 @@
 //   pack     16 rows per lane and step: byte -> code through a 256-byte table, two bit planes
 //   counts   per-group symbol counts -> exclusive scan -> the samples; C[] as in the reference
 //            (unsigned byte order, the delimiter counted where its value falls)
-//   walk 1   the chain is cut where q * A mod 2^k < ids (q = the packed row; the image is the segment's id) and at
-//            the delimiter row; lanes take segment ids until none is left and record {length,
-//            segment run into}
-//   order    pointer jumping over the records: bytes from a segment's start to the text's start
-//   walk 2   the same walks again, now writing bytes (back to front, a dword every four steps) to
-//            where the order step says they go; the segments are handed out stretch by stretch of
-//            the text, the long ones of a stretch first
+//   walk     the chain is cut where q * A mod 2^k < ids (q = the packed row; the image is the segment's id) and at
+//            the delimiter row; lanes take segment ids until none is left, record {length, segment run
+//            into} and append every step's two-bit code to a stream of their own in device memory
+//   order    pointer jumping over the records: bytes, and segments, from a segment's start to the text's
+//            start -- which ranks the segments along the text
+//   copy     lane per 16 bytes of a segment: codes from the streams, bytes to the text, stores coalesced
+//   (-DBWT_PACK_STREAM=0 builds the earlier variant: walk 1 for the lengths only, the order step, then walk 2 --
+//   the same walks again, now writing bytes to where the order step says they go: 22.1 against 18.1 ms on
+//   4 GiB of DNA in 256 KiB blocks)
 // The result is the chain the reference walks (src/inverse_bwt.cpp:48-62), byte for byte; a
 // hand-made block whose LF permutation has several cycles yields the cycle through the delimiter
 // row, like the reference, with the shorter length in lens[].
 #pragma once
+#include <cstddef>
 #include "bwt_inverse.hpp"
 
 namespace bwtgpu {
@@ -69,6 +72,9 @@ struct __attribute__((packed, aligned(1))) PackBytes16 {
 };
 struct __attribute__((packed, aligned(1))) PackBytes4 {
     uint32_t x;
+};
+struct __attribute__((packed, aligned(4))) PackWords2 {
+    uint32_t x, y;
 };
 
 __device__ __forceinline__ uint32_t pack_seg(uint32_t bytes, uint32_t next) { return (bytes << kPackNextBits) | next; }
@@ -210,6 +216,147 @@ __device__ __forceinline__ uint32_t packed_walk(PackShared& sh, uint32_t m, uint
             walking = (at_end | cut) ? 0u : ~0u;
         }
         if (EMIT && (it & 3u) == 3u && cnt >= 4u) store_dword();  // (it & 3) is wave-uniform: a lane holds at most 7 bytes
+    }
+}
+
+// ---- one walk instead of two --------------------------------------------------------------------------
+// Walk 2 repeats every step of walk 1 only because a byte's place in the text is not known before the
+// lengths of all segments are.  With BWT_PACK_STREAM the chain is walked ONCE: a lane appends the bytes of
+// the segments it walks, one after the other and back to front like the text itself, to a stream of its own
+// in device memory (the block's slice of the LF-table area, which nothing else uses while the block is here),
+// and notes per segment where its bytes end up.  The order step then also ranks the segments along the
+// chain, which gives a table sorted by text position, and a copy pass -- one lane per 16 bytes of text,
+// stores coalesced -- looks every piece up and fetches it from the streams.
+#ifndef BWT_PACK_STREAM
+#define BWT_PACK_STREAM 1
+#endif
+constexpr uint32_t kPackOffBytes = 32768u;  // head of the block's area: one word per segment id (where its bytes end), then the streams
+static_assert((kPackIds + 1u) * 4u <= kPackOffBytes, "a word per segment");
+
+// What the LDS of the rank structure holds once the walk is over.
+struct PackPost {
+    uint32_t cnt[kPackIds + 2];   // order: segments from this one to the chain's end; then by rank: 16-byte pieces of the segments before
+    uint32_t pos[kPackIds + 2];   // by rank along the text: first text position of the segment; [segments] = the text's length
+    uint32_t addr[kPackIds + 1];  // by rank: code address of the end of the segment's codes
+    uint16_t owner[kPackMaxRows / 16u + kPackIds + 8u];  // by piece: the rank of the segment it belongs to
+};
+static_assert(sizeof(PackPost) <= 2u * sizeof(uint4) * kPackGroups + sizeof(uint32_t) * (kPackIds + 1u), "fits where planes, samples and records were");
+static_assert(offsetof(PackShared, seg) == offsetof(PackShared, planes) + 2u * sizeof(uint4) * kPackGroups, "... which are one stretch");
+static_assert(offsetof(PackShared, samp) == offsetof(PackShared, planes) + sizeof(uint4) * kPackGroups, "planes and samples are one stretch");
+
+// The single walk: as packed_walk<false> (lengths and links into sh.seg), and every step's two-bit CODE goes
+// to the lane's stream: area + kPackOffBytes + lane * lane_bytes .. + lane_bytes, filled from its top downwards,
+// sixteen codes to a dword, the oldest in the highest bits -- so that, counting codes from the area's start
+// (code address c = bits 2 (c % 16) .. of dword c / 16), a segment's codes lie in text order.
+// segoff[id] = code address of the end of segment id's codes.
+__device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t m, uint32_t drow, uint32_t row0, uint32_t mul,
+                                                       uint32_t inv, uint32_t mask, uint32_t ids, uint8_t* area,
+                                                       uint32_t* segoff, uint32_t lane_bytes) {
+    const uint8_t* const planes = reinterpret_cast<const uint8_t*>(sh.planes);
+    const uint8_t* const samp = reinterpret_cast<const uint8_t*>(sh.samp);
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t id = kNone;
+    uint32_t q = 0, len = 0, hit_next = 0;
+    uint32_t walking = 0;
+    uint32_t acc_lo = 0, acc_hi = 0, cnt = 0;  // codes not yet stored (the oldest in the highest bits), how many (at most 31)
+    const uint32_t lane_lo = kPackOffBytes + (uint32_t)threadIdx.x * lane_bytes;  // byte offsets in the area
+    uint32_t top = lane_lo + lane_bytes;       // one past the dword that holds the oldest code stored last
+    uint32_t wnext = 0, wend = 0;
+    bool more = true;
+    const uint32_t it_cap = 4u * m + 65536u;
+    if (threadIdx.x == 0) {  // the chain's first segment starts where the delimiter row leads
+        const uint32_t q0 = row0 - (row0 > drow ? 1u : 0u);
+        const uint32_t img = __umul24(q0, mul) & mask;
+        segoff[kPackIds] = top * 4u;
+        if (row0 == drow || img < ids) {
+            sh.seg[kPackIds] = pack_seg(0u, row0 == drow ? kPackEnd : img);
+        } else {
+            walking = ~0u;
+            id = kPackIds;
+            q = q0;
+        }
+    }
+    auto store_dword = [&](uint32_t word) {
+        if (top < lane_lo + 4u) {  // the lane's stream is full: the block is left to the general kernels
+            sh.bad = 1;
+            top = lane_lo + lane_bytes;
+        }
+        top -= 4u;
+        *reinterpret_cast<uint32_t*>(area + top) = word;
+    };
+    for (uint32_t it = 0;; ++it) {
+        const uint64_t idle = __ballot(walking == 0u);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (nidle == (uint32_t)kWave || (more && nidle >= kPackGrabBatch)) {  // wave-uniform
+            if (walking == 0u && id != kNone) {  // a finished segment
+                sh.seg[id] = pack_seg(len, hit_next);
+                id = kNone;
+            }
+            if (!more) {  // nobody walks, nothing left: the codes still in registers
+                const uint64_t acc = ((uint64_t)acc_hi << 32) | acc_lo;
+                if (cnt >= 16u) {
+                    store_dword((uint32_t)(acc >> (2u * (cnt - 16u))));
+                    cnt -= 16u;
+                }
+                if (cnt) store_dword(acc_lo << (32u - 2u * cnt));  // the rest in the dword's high bits, where they continue the row
+                return it;
+            }
+            const uint32_t avail = wend - wnext;
+            const uint32_t rank = (uint32_t)__popcll(idle & lanemask_lt());
+            if (walking == 0u && rank < avail) {
+                const uint32_t cand = wnext + rank;
+                const uint32_t q1 = __umul24(cand, inv) & mask;
+                if (q1 < m) {
+                    walking = ~0u;
+                    id = cand;
+                    q = q1;
+                    len = 0;
+                    segoff[cand] = top * 4u - cnt;
+                }
+            }
+            wnext += min(nidle, avail);
+            if (wnext == wend) {  // a new range for the wave
+                uint32_t v = 0;
+                if (lane_id() == 0) v = atomicAdd(&sh.ctr, kPackIdChunk);
+                wnext = wave_read(v, 0);
+                wend = min(wnext + kPackIdChunk, ids);
+                if (wnext >= ids) {
+                    more = false;
+                    wnext = wend = 0;
+                }
+            }
+        }
+        if (it > it_cap) {  // wave-uniform; never
+            sh.bad = 1;
+            return it;
+        }
+        if (walking) {
+            const uint32_t off = (q >> 6) * 16u;
+            const uint4 pl = *reinterpret_cast<const uint4*>(planes + off);
+            const uint32_t up = 63u - (q & 63u);
+            const uint64_t lo = (((uint64_t)pl.y << 32) | pl.x) << up, hi = (((uint64_t)pl.w << 32) | pl.z) << up;
+            const uint32_t s0 = (uint32_t)((int32_t)(uint32_t)(lo >> 32) >> 31);
+            const uint32_t s1 = (uint32_t)((int32_t)(uint32_t)(hi >> 32) >> 31);
+            const uint32_t next_row = *reinterpret_cast<const uint32_t*>(samp + off + ((s0 & 4u) | (s1 & 8u)));
+            const uint32_t same_lo = ~(((uint32_t)lo ^ s0) | ((uint32_t)hi ^ s1));
+            const uint32_t same_hi = ~(((uint32_t)(lo >> 32) ^ s0) | ((uint32_t)(hi >> 32) ^ s1));
+            const uint32_t extra = 1u + (up & ~(s0 | s1));
+            const uint32_t row = next_row + (uint32_t)__popc(same_lo) + (uint32_t)__popc(same_hi) - extra;
+            ++len;
+            acc_hi = __builtin_amdgcn_alignbit(acc_hi, acc_lo, 30);
+            acc_lo = (acc_lo << 2) | (s0 & 1u) | (s1 & 2u);
+            ++cnt;
+            q = row - (row > drow ? 1u : 0u);
+            const uint32_t img = __umul24(q, mul) & mask;
+            const bool at_end = row == drow, cut = img < ids;
+            hit_next = at_end ? kPackEnd : img;
+            walking = (at_end | cut) ? 0u : ~0u;
+        }
+        if ((it & 15u) == 15u && cnt >= 16u) {  // (it & 15) is wave-uniform: a lane holds at most 31 codes
+            const uint64_t acc = ((uint64_t)acc_hi << 32) | acc_lo;
+            store_dword((uint32_t)(acc >> (2u * (cnt - 16u))));
+            cnt -= 16u;
+        }
     }
 }
 
@@ -460,6 +607,192 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         __syncthreads();
         uint8_t* const out_end = a.out + (uint64_t)b * a.out_stride + m;  // one past the text's last byte
 
+#if BWT_PACK_STREAM
+        {
+            uint8_t* const area = reinterpret_cast<uint8_t*>(a.T) + (uint64_t)b * a.tstride * 4u;
+            uint32_t* const segoff = reinterpret_cast<uint32_t*>(area);
+            const uint32_t lane_bytes = ((a.tstride * 4u - kPackOffBytes - 64u) / (uint32_t)kPackThreads) & ~3u;
+            const uint32_t its = packed_walk_stream(sh, m, drow, row0, mul, inv, mask, ids, area, segoff, lane_bytes);
+            __syncthreads();
+            PACK_CLK(4);
+            if (sh.bad) continue;  // workgroup-uniform: a stream ran full (or never: inconsistent tables)
+            PackPost& post = *reinterpret_cast<PackPost*>(sh.planes);  // the rank structure has done its work
+
+            // ---- order: every record becomes bytes (and segments) from its segment's start to the text's start
+            constexpr int E = (kPackIds + 1 + kPackThreads - 1) / kPackThreads;
+            uint32_t own[E], mycnt[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                own[e] = i <= kPackIds ? sh.seg[i] >> kPackNextBits : 0u;
+                mycnt[e] = 1u;
+                if (i <= kPackIds) post.cnt[i] = 1u;
+            }
+            __syncthreads();
+            for (int round = 0; round < (int)kPackNextBits; ++round) {
+                uint32_t nv[E], nc[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                    nv[e] = 0;
+                    nc[e] = mycnt[e];
+                    if (i <= kPackIds) {
+                        const uint32_t word = sh.seg[i];
+                        const uint32_t next = word & kPackEnd;
+                        nv[e] = word;
+                        if (next != kPackEnd) {
+                            const uint32_t w2 = sh.seg[next];
+                            nv[e] = pack_seg((word >> kPackNextBits) + (w2 >> kPackNextBits), w2 & kPackEnd);
+                            nc[e] = mycnt[e] + post.cnt[next];
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                    mycnt[e] = nc[e];
+                    if (i <= kPackIds) {
+                        sh.seg[i] = nv[e];
+                        post.cnt[i] = nc[e];
+                    }
+                }
+                __syncthreads();
+            }
+            const uint32_t first = sh.seg[kPackIds];
+            const uint32_t total = first >> kPackNextBits, nseg = post.cnt[kPackIds];
+            if ((first & kPackEnd) != kPackEnd || total > m || total == 0u || nseg > kPackIds + 1u) continue;  // never for a permutation
+            // the segments on the chain by their rank along the text (the chain's last segment holds the text's start)
+            uint32_t placed = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
+                if (i <= kPackIds) {
+                    const uint32_t word = sh.seg[i], togo = word >> kPackNextBits;
+                    // (a record nobody walked still reads "nothing, chain's end": togo 0)
+                    if ((word & kPackEnd) == kPackEnd && togo != 0u && togo <= total && togo >= own[e] && mycnt[e] <= nseg) {
+                        const uint32_t r = mycnt[e] - 1u;
+                        post.pos[r] = togo - own[e];
+                        post.addr[r] = segoff[i];
+                        ++placed;
+                    }
+                }
+            }
+            if (tid == 0) {
+                post.pos[nseg] = total;
+                sh.ctr = 0;
+            }
+            __syncthreads();
+            if (placed) atomicAdd(&sh.ctr, placed);
+            __syncthreads();
+            if (sh.ctr != nseg) continue;  // workgroup-uniform; never for a permutation: ranks would be missing from the table
+            PACK_CLK(5);
+
+            // ---- pieces: a segment of L bytes is copied as ceil(L / 16) pieces of 16 bytes (the last one moved back so
+            // that it ends with the segment; a segment shorter than 16 bytes is one piece, stored in parts)
+            {
+                constexpr int R = (kPackIds + 1 + kPackThreads - 1) / kPackThreads;
+                uint32_t np[R], sum = 0;
+#pragma unroll
+                for (int e = 0; e < R; ++e) {
+                    const uint32_t r = (uint32_t)tid * R + (uint32_t)e;
+                    np[e] = r < nseg ? (post.pos[r + 1u] - post.pos[r] + 15u) >> 4 : 0u;
+                    sum += np[e];
+                }
+                uint32_t allp;
+                uint32_t run = block_exclusive_scan<kPackThreads>(sum, sh.wsum, allp);
+#pragma unroll
+                // (owner[] reaches into the records' LDS, which the table above was the last to read: all threads are past it)
+                for (int e = 0; e < R; ++e) {
+                    const uint32_t r = (uint32_t)tid * R + (uint32_t)e;
+                    if (r <= nseg) post.cnt[r] = run;
+                    for (uint32_t j = 0; j < np[e]; ++j) post.owner[run + j] = (uint16_t)r;
+                    run += np[e];
+                }
+                __syncthreads();
+#ifdef BWT_PACK_CLOCKS
+                PACK_CLK(7);
+#endif
+                // ---- copy: lane per piece; neighbouring lanes write neighbouring stretches of the text
+                uint8_t* const text = out_end - total;  // (a hand-made block may spell less than m bytes: its text ends where a full one would)
+                const uint32_t* const words = reinterpret_cast<const uint32_t*>(area);
+                // All loads of a batch of pieces first, then all its stores: loads and stores share one in-order counter
+                // of outstanding operations here, so a wait for a load issued after a store also sits out that store's
+                // round trip -- once per batch this way, not once per piece.
+                constexpr int U = 12;  // pieces of a batch per lane (a block has at most 24 per lane)
+                for (uint32_t base = 0; base < allp; base += U * kPackThreads) {
+                    uint32_t w0[U], w1[U], sh2[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t pc = min(base + (uint32_t)u * kPackThreads + (uint32_t)tid, allp - 1u);
+                        const uint32_t lo = post.owner[pc];
+                        const uint32_t L = post.pos[lo + 1u] - post.pos[lo];
+                        uint32_t start = 16u * (pc - post.cnt[lo]);
+                        if (L >= 16u) start = min(start, L - 16u);
+                        const uint32_t ca = post.addr[lo] - L + start;  // code address of the piece's first code
+                        const PackWords2 ww = *reinterpret_cast<const PackWords2*>(words + (ca >> 4));  // one request for both words
+                        w0[u] = ww.x;
+                        w1[u] = ww.y;
+                        sh2[u] = (ca & 15u) * 2u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t p = base + (uint32_t)u * kPackThreads + (uint32_t)tid;
+                        if (p >= allp) break;
+                        const uint32_t lo = post.owner[p];
+                        const uint32_t P = post.pos[lo], L = post.pos[lo + 1u] - P;
+                        uint32_t start = 16u * (p - post.cnt[lo]);
+                        if (L >= 16u) start = min(start, L - 16u);
+                        uint8_t* const dst = text + P + start;
+                        const uint32_t codes = __builtin_amdgcn_alignbit(w1[u], w0[u], sh2[u]);
+                        uint32_t d[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {  // four codes -> the selector of a byte permute over the four byte values
+                            const uint32_t c = (codes >> (8 * k)) & 255u;
+                            const uint32_t sel = (c & 3u) | ((c & 0xCu) << 6) | ((c & 0x30u) << 12) | ((c & 0xC0u) << 18);
+                            d[k] = __builtin_amdgcn_perm(0u, cbytes, sel);
+                        }
+                        if (L >= 16u) {
+                            PackBytes16 o;
+                            o.x = d[0]; o.y = d[1]; o.z = d[2]; o.w = d[3];
+                            *reinterpret_cast<PackBytes16*>(dst) = o;
+                        } else {
+                            const uint32_t a8 = L & 8u, a4 = L & 4u;  // (no indexing of d[] by a run-time value: it would live in scratch)
+                            const uint32_t x4 = a8 ? d[2] : d[0];
+                            const uint32_t rest = a8 ? (a4 ? d[3] : d[2]) : (a4 ? d[1] : d[0]);
+                            uint32_t at = a8;
+                            if (a8) {
+                                reinterpret_cast<PackBytes4*>(dst)->x = d[0];
+                                reinterpret_cast<PackBytes4*>(dst + 4)->x = d[1];
+                            }
+                            if (a4) {
+                                reinterpret_cast<PackBytes4*>(dst + at)->x = x4;
+                                at += 4u;
+                            }
+                            if (L & 2u) {
+                                dst[at] = (uint8_t)rest;
+                                dst[at + 1u] = (uint8_t)(rest >> 8);
+                            }
+                            if (L & 1u) dst[at + (L & 2u)] = (uint8_t)(rest >> (8u * (L & 2u)));
+                        }
+                    }
+                }
+            }
+            PACK_CLK(6);
+            (void)its;
+#ifdef BWT_PACK_CLOCKS
+            if (tid == 0 && b == 0)
+                printf("packed inverse, block 0 (%u rows): sample %u pack %u delete %u counts %u walk %u order %u pieces %u copy %u ticks; wave 0: %u iterations, %u segments\n", n,
+                       clk_[0], clk_[1], clk_[2], clk_[3], clk_[4], clk_[5], clk_[7], clk_[6], its, nseg);
+#endif
+            if (tid == 0) {
+                a.lens[b] = total;
+                a.mode[b] = kModeDone;
+                atomicAdd(&a.queue[3], 1u);
+            }
+            continue;
+        }
+#endif
         const uint32_t its1 = packed_walk<false>(sh, m, drow, row0, mul, inv, mask, ids, cbytes, out_end, 0u, 0u);
         __syncthreads();
         PACK_CLK(4);
