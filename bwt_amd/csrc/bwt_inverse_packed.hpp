@@ -256,7 +256,7 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
     const uint8_t* const samp = reinterpret_cast<const uint8_t*>(sh.samp);
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t id = kNone;
-    uint32_t q = 0, len = 0, hit_next = 0;
+    uint32_t q = 0, first_ca = 0, hit_next = 0;  // first_ca: where the segment's codes end (its first code's address + 1)
     uint32_t walking = 0;
     uint32_t acc_lo = 0, acc_hi = 0, cnt = 0;  // codes not yet stored (the oldest in the highest bits), how many (at most 31)
     const uint32_t lane_lo = kPackOffBytes + (uint32_t)threadIdx.x * lane_bytes;  // byte offsets in the area
@@ -267,7 +267,7 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
     if (threadIdx.x == 0) {  // the chain's first segment starts where the delimiter row leads
         const uint32_t q0 = row0 - (row0 > drow ? 1u : 0u);
         const uint32_t img = __umul24(q0, mul) & mask;
-        segoff[kPackIds] = top * 4u;
+        segoff[kPackIds] = first_ca = top * 4u;
         if (row0 == drow || img < ids) {
             sh.seg[kPackIds] = pack_seg(0u, row0 == drow ? kPackEnd : img);
         } else {
@@ -284,12 +284,14 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
         top -= 4u;
         *reinterpret_cast<uint32_t*>(area + top) = word;
     };
-    for (uint32_t it = 0;; ++it) {
+    for (uint32_t it = 0;;) {
+#pragma unroll 1
+      for (uint32_t k = 0; k < 16u; ++k, ++it) {  // sixteen steps, then the lanes that have sixteen codes store them
         const uint64_t idle = __ballot(walking == 0u);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (nidle == (uint32_t)kWave || (more && nidle >= kPackGrabBatch)) {  // wave-uniform
             if (walking == 0u && id != kNone) {  // a finished segment
-                sh.seg[id] = pack_seg(len, hit_next);
+                sh.seg[id] = pack_seg(first_ca - (top * 4u - cnt), hit_next);  // (a code per step)
                 id = kNone;
             }
             if (!more) {  // nobody walks, nothing left: the codes still in registers
@@ -310,8 +312,7 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
                     walking = ~0u;
                     id = cand;
                     q = q1;
-                    len = 0;
-                    segoff[cand] = top * 4u - cnt;
+                    segoff[cand] = first_ca = top * 4u - cnt;
                 }
             }
             wnext += min(nidle, avail);
@@ -326,10 +327,6 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
                 }
             }
         }
-        if (it > it_cap) {  // wave-uniform; never
-            sh.bad = 1;
-            return it;
-        }
         if (walking) {
             const uint32_t off = (q >> 6) * 16u;
             const uint4 pl = *reinterpret_cast<const uint4*>(planes + off);
@@ -342,7 +339,6 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
             const uint32_t same_hi = ~(((uint32_t)(lo >> 32) ^ s0) | ((uint32_t)(hi >> 32) ^ s1));
             const uint32_t extra = 1u + (up & ~(s0 | s1));
             const uint32_t row = next_row + (uint32_t)__popc(same_lo) + (uint32_t)__popc(same_hi) - extra;
-            ++len;
             acc_hi = __builtin_amdgcn_alignbit(acc_hi, acc_lo, 30);
             acc_lo = (acc_lo << 2) | (s0 & 1u) | (s1 & 2u);
             ++cnt;
@@ -352,7 +348,12 @@ __device__ __forceinline__ uint32_t packed_walk_stream(PackShared& sh, uint32_t 
             hit_next = at_end ? kPackEnd : img;
             walking = (at_end | cut) ? 0u : ~0u;
         }
-        if ((it & 15u) == 15u && cnt >= 16u) {  // (it & 15) is wave-uniform: a lane holds at most 31 codes
+      }
+        if (it > it_cap) {  // wave-uniform; never
+            sh.bad = 1;
+            return it;
+        }
+        if (cnt >= 16u) {  // (a lane holds at most 31 codes)
             const uint64_t acc = ((uint64_t)acc_hi << 32) | acc_lo;
             store_dword((uint32_t)(acc >> (2u * (cnt - 16u))));
             cnt -= 16u;
