@@ -619,68 +619,57 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
             if (sh.bad) continue;  // workgroup-uniform: a stream ran full (or never: inconsistent tables)
             PackPost& post = *reinterpret_cast<PackPost*>(sh.planes);  // the rank structure has done its work
 
-            // ---- order: every record becomes bytes (and segments) from its segment's start to the text's start
+            // ---- order: every record becomes bytes, and segments, from its segment's start to the text's start.
+            // Records of 8 bytes {bytes << 13 | next, segments} over cnt[] and pos[]; a thread keeps its own ones in registers.
             constexpr int E = (kPackIds + 1 + kPackThreads - 1) / kPackThreads;
-            uint32_t own[E], mycnt[E];
+            uint2* const rec = reinterpret_cast<uint2*>(&post);
+            static_assert(sizeof(uint2) * (kPackIds + 1u) <= offsetof(PackPost, addr), "the records end before addr[]");
+            uint2 mine[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
-                own[e] = i <= kPackIds ? sh.seg[i] >> kPackNextBits : 0u;
-                mycnt[e] = 1u;
-                if (i <= kPackIds) post.cnt[i] = 1u;
+                mine[e] = make_uint2(i <= kPackIds ? sh.seg[i] : pack_seg(0u, kPackEnd), 1u);
+                if (i <= kPackIds) rec[i] = mine[e];
             }
             __syncthreads();
             for (int round = 0; round < (int)kPackNextBits; ++round) {
-                uint32_t nv[E], nc[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
-                    nv[e] = 0;
-                    nc[e] = mycnt[e];
-                    if (i <= kPackIds) {
-                        const uint32_t word = sh.seg[i];
-                        const uint32_t next = word & kPackEnd;
-                        nv[e] = word;
-                        if (next != kPackEnd) {
-                            const uint32_t w2 = sh.seg[next];
-                            nv[e] = pack_seg((word >> kPackNextBits) + (w2 >> kPackNextBits), w2 & kPackEnd);
-                            nc[e] = mycnt[e] + post.cnt[next];
-                        }
+                    const uint32_t next = mine[e].x & kPackEnd;
+                    if (next != kPackEnd) {
+                        const uint2 w2 = rec[next];
+                        mine[e] = make_uint2(pack_seg((mine[e].x >> kPackNextBits) + (w2.x >> kPackNextBits), w2.x & kPackEnd), mine[e].y + w2.y);
                     }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
-                    mycnt[e] = nc[e];
-                    if (i <= kPackIds) {
-                        sh.seg[i] = nv[e];
-                        post.cnt[i] = nc[e];
-                    }
+                    if (i <= kPackIds) rec[i] = mine[e];
                 }
                 __syncthreads();
             }
-            const uint32_t first = sh.seg[kPackIds];
-            const uint32_t total = first >> kPackNextBits, nseg = post.cnt[kPackIds];
-            if ((first & kPackEnd) != kPackEnd || total > m || total == 0u || nseg > kPackIds + 1u) continue;  // never for a permutation
-            // the segments on the chain by their rank along the text (the chain's last segment holds the text's start)
+            const uint2 first = rec[kPackIds];
+            const uint32_t total = first.x >> kPackNextBits, nseg = first.y;
+            if ((first.x & kPackEnd) != kPackEnd || total > m || total == 0u || nseg > kPackIds + 1u) continue;  // never for a permutation
+            __syncthreads();  // everybody has read the first record: the tables go where the records are
+            // The segments on the chain by their rank along the text (the chain's last segment holds the text's start):
+            // the segment of rank r covers text positions pos[r] .. pos[r + 1], its codes end at code address addr[r].
             uint32_t placed = 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint32_t i = (uint32_t)tid + (uint32_t)e * kPackThreads;
-                if (i <= kPackIds) {
-                    const uint32_t word = sh.seg[i], togo = word >> kPackNextBits;
-                    // (a record nobody walked still reads "nothing, chain's end": togo 0)
-                    if ((word & kPackEnd) == kPackEnd && togo != 0u && togo <= total && togo >= own[e] && mycnt[e] <= nseg) {
-                        const uint32_t r = mycnt[e] - 1u;
-                        post.pos[r] = togo - own[e];
-                        post.addr[r] = segoff[i];
-                        ++placed;
-                    }
+                const uint32_t togo = mine[e].x >> kPackNextBits;
+                // (a record nobody walked still reads "nothing, chain's end": togo 0)
+                if (i <= kPackIds && (mine[e].x & kPackEnd) == kPackEnd && togo != 0u && togo <= total && mine[e].y <= nseg) {
+                    const uint32_t r = mine[e].y - 1u;
+                    post.pos[r + 1u] = togo;
+                    post.addr[r] = segoff[i];
+                    ++placed;
                 }
             }
             if (tid == 0) {
-                post.pos[nseg] = total;
+                post.pos[0] = 0;
                 sh.ctr = 0;
             }
             __syncthreads();
