@@ -50,7 +50,10 @@ constexpr int kLdsThreads = 1024;
 constexpr int kLdsWaves = kLdsThreads / kWave;
 constexpr uint32_t kLdsMaxLen2 = 262144u;        // two bits per symbol: 64 KB of packed text
 constexpr uint32_t kLdsMaxLen8 = 65536u;         // bytes
-constexpr uint32_t kLdsMinLen = 16384u;          // shorter blocks: the general kernels run several per compute unit
+// Shorter blocks than this go to the general kernels.  Measured on 1 GiB of ACGT text, this kernel / the general ones:
+// 2 KiB blocks 44 / 60 ms, 4 KiB 22 / 38, 8 KiB 11.1 / 26.7, 16 KiB 7.8 / 20.3 (random bytes alike) -- a workgroup per
+// block wins at every size; below 2 KiB the one-wave-per-block kernel for short blocks is near.
+constexpr uint32_t kLdsMinLen = 2048u;
 constexpr uint32_t kLdsTextWords = 16384u + 8u;  // the text, the virtual symbols behind it, and what a window there reads
 constexpr int kLdsFineBits = 13;
 constexpr uint32_t kLdsFine = 1u << kLdsFineBits;

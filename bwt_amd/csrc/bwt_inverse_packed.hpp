@@ -41,11 +41,11 @@ namespace bwtgpu {
 constexpr int kPackThreads = 1024;
 constexpr uint32_t kPackMaxRows = 262144u + 1u;  // block_size + 1 at most: the bit planes of more rows do not fit
 // Shorter blocks are left to the table kernels, which run several per compute unit: here a block has a
-// compute unit to itself, and the end of each walk -- the last lanes finishing the longest segments --
+// compute unit to itself, and the end of the walk -- the last lanes finishing the longest segments --
 // does not shrink with the block.  Measured on 1 GiB of ACGT text (this kernel / table kernels):
-// 16 KiB blocks 21.6 / 11.3 ms, 32 KiB 12.9 / 11.0, 48 KiB 9.2 / 11.0, 64 KiB 7.8 / 11.0, 128 KiB 6.3 / 11.3,
-// 256 KiB 5.7 / 10.8.
-constexpr uint32_t kPackMinRows = 49152u;
+// 8 KiB blocks 24.8 / 11.3 ms, 16 KiB 15.3 / 11.2, 24 KiB 11.6 / 10.7, 32 KiB 9.7 / 11.0, 48 KiB 8.3 / 11.0,
+// 64 KiB 7.0 / 11.0, 128 KiB 5.0 / 11.3, 256 KiB 4.0 / 10.8.
+constexpr uint32_t kPackMinRows = 28672u;
 constexpr uint32_t kPackGroups = (kPackMaxRows + 63u) / 64u;  // groups of 64 rows while the delimiter row is still in
 constexpr uint32_t kPackIds = 7936u;             // segment ids (LDS holds one record each); id kPackIds = the chain's first segment
 constexpr uint32_t kPackEnd = 8191u;             // "runs into the delimiter row"
@@ -79,7 +79,10 @@ struct __attribute__((packed, aligned(4))) PackWords2 {
 
 __device__ __forceinline__ uint32_t pack_seg(uint32_t bytes, uint32_t next) { return (bytes << kPackNextBits) | next; }
 
-constexpr uint32_t kPackGrabBatch = 8;   // lanes of a wave that wait for a segment before the wave hands ids out
+#ifndef BWT_PACK_GRAB
+#define BWT_PACK_GRAB 12
+#endif
+constexpr uint32_t kPackGrabBatch = BWT_PACK_GRAB;   // lanes of a wave that wait for a segment before the wave hands ids out
 constexpr uint32_t kPackIdChunk = 64;    // ids a wave takes from the workgroup's counter at a time
 constexpr uint32_t kPackLong = 48;       // walk 2 hands out the segments of at least this many bytes first
 

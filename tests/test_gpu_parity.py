@@ -208,7 +208,8 @@ def test_text_in_lds_forward(orc, forward_path):
     def draw(symbols, n):
         return np.frombuffer(bytes(symbols), np.uint8)[rng.integers(0, len(symbols), size=n)]
 
-    for n in [16384, 16385, 16399, 16400, 16401, 20000, 65535, 65536, 65537, 131072, 262143, 262144]:
+    for n in [2048, 2049, 2063, 3000, 4096, 5000, 8191, 12345, 16384, 16385, 16399, 16400, 16401, 20000, 28671, 28672, 65535, 65536, 65537, 131072,
+              262143, 262144]:
         for symbols, delim in [(b"ACGT", 0), (b"ACGT", ord("D")), (b"ACGT", ord("H")), (b"ACGT", 255), (b"ab", ord("a") + 3),
                                (b"ab", 0), (b"x", 7), (b"x", 200), (bytes([0, 1, 2]), 3), (bytes([1, 254, 255]), 0),
                                (bytes([1, 254, 255]), 100)]:
@@ -216,7 +217,7 @@ def test_text_in_lds_forward(orc, forward_path):
                 continue
             cases.append((draw(symbols, n), delim))
     # bytes: uniform, few values, with the delimiter just below / above / between
-    for n in [16384, 30000, 65535, 65536]:
+    for n in [2048, 2500, 4097, 10000, 16384, 30000, 65535, 65536]:
         cases.append((rng.integers(0, 255, size=n, dtype=np.uint8), 255))
         cases.append((rng.integers(1, 256, size=n, dtype=np.uint8), 0))
         cases.append((rng.integers(0, 100, size=n, dtype=np.uint8) * 2, 101))  # the delimiter between the byte values

@@ -21,7 +21,7 @@ orc = oracle.oracle()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 BIG_ONLY = len(sys.argv) > 3 and sys.argv[3] == "big"  # only long blocks and many-block batches
 ORIGIN_ONLY = len(sys.argv) > 3 and sys.argv[3] == "origin"  # the origin-pointer format (sorted rotations), forward and back
-LDS_ONLY = len(sys.argv) > 3 and sys.argv[3] == "lds"  # only the shapes the in-LDS kernels take: blocks of 16-256 KiB, batch path
+LDS_ONLY = len(sys.argv) > 3 and sys.argv[3] == "lds"  # only the shapes the in-LDS kernels take: blocks of 2-256 KiB, batch path
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 nrng = np.random.default_rng(rng.randrange(1 << 30))
 prng = random.Random(12345)  # forward path per trial, drawn apart so that the inputs do not depend on it
@@ -86,8 +86,9 @@ for t in range(trials):
         # blocks of 16 KiB .. 256 KiB (at most 64 KiB unless the alphabet is small: the text then fits the LDS both
         # ways), a handful of them plus a ragged tail, through the batch kernels
         small = rng.random() < 0.6
-        bs = rng.choice([16384, 16385, 20000, 32768, 49151, 49152, 65535, 65536, 65537, 100000, 131072, 262143, 262144]) if small \
-            else rng.choice([16384, 20000, 32768, 49151, 49152, 60000, 65535, 65536])
+        bs = rng.choice([2048, 2049, 3000, 4096, 6000, 8192, 12000, 16384, 16385, 20000, 28671, 28672, 32768, 49151, 49152, 65535, 65536, 65537, 100000,
+                         131072, 262143, 262144]) if small \
+            else rng.choice([2048, 2500, 4096, 7000, 8192, 16384, 20000, 32768, 49151, 49152, 60000, 65535, 65536])
         n = bs * rng.randrange(1, 5) + rng.choice([0, 1, 17, bs // 2, bs - 1])
         n = min(n, 700000)
         data, kind, sigma, base = make(n)
