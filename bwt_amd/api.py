@@ -42,7 +42,7 @@ SYMBOLS = [
     "bwtgpu_pipeline_submit", "bwtgpu_pipeline_collect", "bwtgpu_pipeline_destroy",
     "bwtgpu_pipeline_upload_presence", "bwtgpu_forward_batch_static", "bwtgpu_time_resident",
     "bwtgpu_pipeline_reserve", "bwtgpu_pipeline_stage", "bwtgpu_pipeline_stage_wait", "bwtgpu_pipeline_presence",
-    "bwtgpu_pipeline_submit_resident",
+    "bwtgpu_pipeline_submit_resident", "bwtgpu_pipeline_run",
     "bwtgpu_inverse_origin_workspace_bytes", "bwtgpu_inverse_origin_batch_device", "bwtgpu_inverse_origin_batch",
     "bwtgpu_forward_origin_workspace_bytes", "bwtgpu_forward_origin_batch_device", "bwtgpu_forward_origin_batch",
 ]
@@ -116,6 +116,8 @@ def lib() -> ctypes.CDLL:
     L.bwtgpu_pipeline_collect.restype = _i
     L.bwtgpu_pipeline_upload_presence.argtypes = [_vp, _i, _sz, ctypes.POINTER(ctypes.c_uint32)]
     L.bwtgpu_pipeline_upload_presence.restype = _i
+    L.bwtgpu_pipeline_run.argtypes = [_vp, _i, _sz, ctypes.c_uint8, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.bwtgpu_pipeline_run.restype = _i
     L.bwtgpu_pipeline_reserve.argtypes, L.bwtgpu_pipeline_reserve.restype = [_vp, _sz], _i
     L.bwtgpu_pipeline_stage.argtypes, L.bwtgpu_pipeline_stage.restype = [_vp, _i, _sz, _sz], _i
     L.bwtgpu_pipeline_stage_wait.argtypes, L.bwtgpu_pipeline_stage_wait.restype = [_vp, _i], _i

@@ -72,6 +72,8 @@ constexpr int kLdsPosBits = 19;                  // positions 0 .. 262144
 constexpr uint32_t kLdsPosMask = (1u << 19) - 1u;
 constexpr int kLdsCodeShift = 29;                // a scratch word: position | bucket << 19 | (two-bit text) code of the symbol before << 29
 constexpr int kLdsDepth = 8;                     // windows two suffixes are compared over before the block is given up
+constexpr uint32_t kLdsMaxDups = 110;            // byte alphabets: colliding sample windows (of 1024) up to which a block is tried
+constexpr uint32_t kLdsMaxFlat = 32;             // sample windows (of 1024) of one repeated byte up to which a block is tried
 constexpr uint32_t kLdsMaxPeriod = 4096;         // whole-block periods up to here are looked for before anything else
 constexpr int kLdsClockSlot = 32;                // phase clocks: u64 words from queue + 2 * kLdsClockSlot
 
@@ -102,7 +104,7 @@ struct LdsShared {
     uint32_t wsum[kLdsWaves];
     uint64_t ball[4];
     uint32_t cb[4];                // code -> byte
-    uint32_t blk, bad, next;
+    uint32_t blk, bad, next, dups, flat;
     uint32_t period_cand, period_bad;  // detect_block_period's words
 };
 static_assert(sizeof(LdsShared) <= 160u * 1024u, "one workgroup's LDS");
@@ -656,6 +658,30 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     return sh.bad == 0u;
 }
 
+// The sample every block starts with: 16 bytes per lane spread over the block mark the alphabet (sh.present), and two
+// counts say what the bytes are like.  sh.dups: how many of the 1024 lanes' first four bytes fall on a value another lane
+// has -- text and structured binary data repeat their four-byte strings (185-1023 lanes collide over the Canterbury files
+// at any block size), uniform bytes over sixteen values or more do not (40-90, nearly all of them table slots shared by
+// chance).  sh.flat: how many lanes read one byte value sixteen times -- long runs (scanned images, zero-filled tables)
+// tie deeper than the in-LDS sort follows, whatever the alphabet.  Kept out of line: the kernel around it sits at its
+// register limit, and the sample's temporaries moved its allocation for the worse.
+__device__ __attribute__((noinline)) void lds_sample_block(const uint8_t* __restrict__ s, uint32_t len, LdsShared& sh) {
+    const int tid = threadIdx.x;
+    const uint32_t at = (uint32_t)(((uint64_t)tid * (len - 16u)) / (kLdsThreads - 1u));
+    const LdsBytes16 x = *reinterpret_cast<const LdsBytes16*>(s + at);
+    const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sh.present[(d[k >> 2] >> (8 * (k & 3))) & 255u] = 1;
+    if (tid == 0) sh.dups = sh.flat = 0;
+    for (uint32_t i = (uint32_t)tid; i < kLdsFine; i += kLdsThreads) sh.u.fine[i] = 0;
+    __syncthreads();
+    const uint32_t before = atomicAdd(&sh.u.fine[(d[0] * 0x9E3779B1u) >> (32 - kLdsFineBits)], 1u);
+    const uint64_t hit = __ballot(before != 0u);
+    if (lane_id() == 0 && hit) atomicAdd(&sh.dups, (uint32_t)__popcll(hit));
+    const uint64_t run = __ballot(d[0] == (d[0] & 255u) * 0x01010101u && d[1] == d[0] && d[2] == d[0] && d[3] == d[0]);
+    if (lane_id() == 0 && run) atomicAdd(&sh.flat, (uint32_t)__popcll(run));
+}
+
 // Blocks of kLdsMinLen .. kLdsMaxLen2 bytes from the queue (queue[7]); a block this kernel does not
 // finish is appended to a.normal (queue[5] counts), which the general kernel's next launch works through.
 __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a) {
@@ -681,14 +707,7 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
         uint8_t* __restrict__ out = a.out + (uint64_t)b * ((uint64_t)a.block_size + 1u);
         bool done = false, tried = false;
         if (len >= kLdsMinLen && len <= kLdsMaxLen2) {  // workgroup-uniform
-            // ---- the alphabet, from 16 bytes per lane spread over the block
-            {
-                const uint32_t at = (uint32_t)(((uint64_t)tid * (len - 16u)) / (kLdsThreads - 1u));
-                const LdsBytes16 x = *reinterpret_cast<const LdsBytes16*>(s + at);
-                const uint32_t d[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) sh.present[(d[k >> 2] >> (8 * (k & 3))) & 255u] = 1;
-            }
+            lds_sample_block(s, len, sh);  // the alphabet, and the two counts that keep hopeless blocks away
             __syncthreads();
             const bool present = tid < 256 && sh.present[tid] != 0;
             const uint64_t bal = __ballot(present);
@@ -703,8 +722,10 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
                 if (i < w) below += c;
             }
             const bool delim_seen = ((sh.ball[a.delim >> 6] >> (a.delim & 63u)) & 1ull) != 0ull;
-            if (!delim_seen && sigma == 1u) {
-                tried = true;  // one byte value throughout (as far as the sample shows): a run, the other launch's business
+            if (!delim_seen && (sigma == 1u || (sigma <= 4u && sh.flat > kLdsMaxFlat))) {
+                // one byte value throughout (as far as the sample shows) or in long stretches: runs, the other launches'
+                // business -- the common-case one's first, which puts off what it has to: a block like that takes its
+                // time there, and two launches that each wait for one of them take twice as long as one with both
             } else if (!delim_seen && sigma <= 4u) {
                 if (tid < 256) {
                     const uint32_t code = below + (uint32_t)__popcll(bal & lanemask_lt());
@@ -719,7 +740,9 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
                 pc.lap(kLdsClockSlot + 0);
                 tried = true;
                 done = lds_forward_block<2>(s, len, a.delim, out, sa, sh, sigma, dr, cbytes, pc);
-            } else if (!delim_seen && len <= kLdsMaxLen8) {
+            } else if (!delim_seen && len <= kLdsMaxLen8 && sh.dups <= kLdsMaxDups) {
+                // (bytes whose four-byte strings repeat would fill single sub-bins of the bucket sort beyond what it settles,
+                // and the block would be given up after most of the work: left to the general kernels untried)
                 pc.lap(kLdsClockSlot + 0);
                 tried = true;
                 done = lds_forward_block<8>(s, len, a.delim, out, sa, sh, 256u, a.delim, 0u, pc);

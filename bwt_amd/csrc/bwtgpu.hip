@@ -582,10 +582,13 @@ int forward_grid_coop(const Device& d, const uint8_t* d_in, size_t total_len, si
 
 // d_rows != nullptr: rotations instead of suffixes (no delimiter; d_out takes total_len bytes, d_rows the row of
 // every block's rotation 0).  That variant is always driven from the host.
+// may_block: the caller is going to wait for the result anyway (a host-pointer call, a timing call, a
+// submit-and-collect): the host-driven sequence then serves it sooner than the resident kernel (kernel
+// boundaries cost less than grid barriers).
 int forward_grid(const Device& d, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
-                 uint8_t* d_out, void* d_workspace, hipStream_t s, uint32_t* d_rows = nullptr) {
+                 uint8_t* d_out, void* d_workspace, hipStream_t s, uint32_t* d_rows = nullptr, bool may_block = false) {
     const bool cyclic = d_rows != nullptr;
-    if (!cyclic && !grid_host_driven()) {
+    if (!cyclic && !may_block && !grid_host_driven()) {
         const int rc = forward_grid_coop(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
         if (rc <= 0) return rc;
     }
@@ -928,9 +931,17 @@ size_t bwtgpu_inverse_workspace_bytes(int device, size_t total, size_t block_siz
     return inv_geom(*g_dev[device], total, block_size).bytes;
 }
 
+static int forward_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
+                          uint8_t* d_out, void* d_workspace, size_t workspace_bytes, void* stream, bool may_block);
+
 int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size,
                                 uint8_t delimiter, uint8_t* d_out, void* d_workspace, size_t workspace_bytes,
                                 void* stream) {
+    return forward_device(device, d_in, total_len, block_size, delimiter, d_out, d_workspace, workspace_bytes, stream, false);
+}
+
+static int forward_device(int device, const uint8_t* d_in, size_t total_len, size_t block_size, uint8_t delimiter,
+                          uint8_t* d_out, void* d_workspace, size_t workspace_bytes, void* stream, bool may_block) {
     int rc = check_device(device);
     if (rc) return rc;
     if (block_size == 0) return fail(BWTGPU_ERR_INVALID, "block_size must be greater than 0");
@@ -949,7 +960,7 @@ int bwtgpu_forward_batch_device(int device, const uint8_t* d_in, size_t total_le
     HIP_TRY(hipSetDevice(device));
     if (g.grid_path) {
         HIP_TRY(hipMemsetAsync(d_workspace, 0, kHeaderBytes, s));
-        return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s);
+        return forward_grid(d, d_in, total_len, block_size, delimiter, d_out, d_workspace, s, nullptr, may_block);
     }
     if (block_size > kBlockKernelMaxBlock)
         return fail(BWTGPU_ERR_INVALID, "a batch of blocks above %zu bytes may hold at most 2^31 bytes (%zu given): split it",
@@ -1270,8 +1281,8 @@ int bwtgpu_forward_batch(int device, const uint8_t* in, size_t total_len, size_t
         if ((rc = grow(&d.d_out, &d.out_cap, sub + nb))) return rc;
         if ((rc = grow(&d.d_ws, &d.ws_cap, g.bytes))) return rc;
         HIP_TRY(hipMemcpyAsync(d.d_in, in + off, sub, hipMemcpyHostToDevice, d.stream));
-        rc = bwtgpu_forward_batch_device(device, (const uint8_t*)d.d_in, sub, block_size, delimiter,
-                                         (uint8_t*)d.d_out, d.d_ws, d.ws_cap, d.stream);
+        rc = forward_device(device, (const uint8_t*)d.d_in, sub, block_size, delimiter, (uint8_t*)d.d_out, d.d_ws, d.ws_cap,
+                            d.stream, true);  // (this call waits for the result anyway)
         if (rc) return rc;
         const size_t out_off = (off / block_size) * (block_size + 1);
         HIP_TRY(hipMemcpyAsync(out + out_off, d.d_out, sub + nb, hipMemcpyDeviceToHost, d.stream));
@@ -1432,8 +1443,8 @@ int bwtgpu_time_resident(int device, const uint8_t* in, size_t total_len, size_t
     for (int dir = 0; dir < 2; ++dir) {
         for (int it = 0; it <= reps; ++it) {  // pass 0 is the warm-up
             if (it == 1 && (rc = guarded(hip_ok(hipEventRecord(ev[0], d.stream))))) return rc;
-            rc = dir == 0 ? bwtgpu_forward_batch_device(device, (const uint8_t*)d.d_in, total_len, block_size, delimiter,
-                                                        (uint8_t*)d.d_out, d.d_ws, d.ws_cap, d.stream)
+            rc = dir == 0 ? forward_device(device, (const uint8_t*)d.d_in, total_len, block_size, delimiter,
+                                           (uint8_t*)d.d_out, d.d_ws, d.ws_cap, d.stream, true)  // (what a caller that waits sees)
                           : bwtgpu_inverse_batch_device(device, (const uint8_t*)d.d_out, fwd_bytes, block_size, delimiter,
                                                         d_back, (uint32_t*)d.d_aux, d.d_ws, d.ws_cap, d.stream);
             if (guarded(rc)) return rc;
@@ -1553,7 +1564,7 @@ size_t bwtgpu_pipeline_input_capacity(const bwtgpu_pipeline* p) { return p ? p->
 namespace {
 // The transform of `bytes` bytes into slot s's output: from d_src if given (already on the device), else from
 // the slot's own input buffer, uploaded first unless bwtgpu_pipeline_upload_presence has done that.
-int pipeline_run(bwtgpu_pipeline* p, int slot, const uint8_t* d_src, size_t bytes, uint8_t delimiter) {
+int pipeline_run(bwtgpu_pipeline* p, int slot, const uint8_t* d_src, size_t bytes, uint8_t delimiter, bool may_block = false) {
     PipeSlot& s = p->slots[(size_t)slot];
     if (s.busy) return fail(BWTGPU_ERR_INVALID, "slot %d submitted again before it was collected", slot);
     if (bytes > p->in_cap) return fail(BWTGPU_ERR_INVALID, "%zu bytes exceed the slab capacity %zu", bytes, p->in_cap);
@@ -1579,8 +1590,7 @@ int pipeline_run(bwtgpu_pipeline* p, int slot, const uint8_t* d_src, size_t byte
         if (!uploaded) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, bytes, hipMemcpyHostToDevice, s.stream));
         int rc;
         if (p->direction == BWTGPU_FORWARD) {
-            rc = bwtgpu_forward_batch_device(p->device, d_src, bytes, p->block_size, delimiter, s.d_out, s.d_ws,
-                                             s.ws_cap, s.stream);
+            rc = forward_device(p->device, d_src, bytes, p->block_size, delimiter, s.d_out, s.d_ws, s.ws_cap, s.stream, may_block);
             if (rc) return rc;
             const size_t nb = (bytes + p->block_size - 1) / p->block_size;
             HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, bytes + nb, hipMemcpyDeviceToHost, s.stream));
@@ -1603,6 +1613,12 @@ int pipeline_run(bwtgpu_pipeline* p, int slot, const uint8_t* d_src, size_t byte
 int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter) {
     if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
     return pipeline_run(p, slot, nullptr, bytes, delimiter);
+}
+
+int bwtgpu_pipeline_run(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter, const uint8_t** out, size_t* out_bytes) {
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return fail(BWTGPU_ERR_INVALID, "bad pipeline slot");
+    const int rc = pipeline_run(p, slot, nullptr, bytes, delimiter, true);
+    return rc ? rc : bwtgpu_pipeline_collect(p, slot, out, out_bytes);
 }
 
 int bwtgpu_pipeline_reserve(bwtgpu_pipeline* p, size_t nslabs) {

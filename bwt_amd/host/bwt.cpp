@@ -112,8 +112,7 @@ static int forward_single_slab(const char* input_file, const char* output_file, 
         writer.reserve_output(1 + got + (got + block_size - 1) / block_size);  // header, bytes, one delimiter per block
         const uint8_t* out = nullptr;
         size_t n = 0;
-        if (bwtgpu_pipeline_submit(p, 0, got, static_cast<uint8_t>(delimiter)) != BWTGPU_OK ||
-            bwtgpu_pipeline_collect(p, 0, &out, &n) != BWTGPU_OK) {
+        if (bwtgpu_pipeline_run(p, 0, got, static_cast<uint8_t>(delimiter), &out, &n) != BWTGPU_OK) {
             std::cerr << "Error: " << bwtgpu_last_error() << std::endl;
             reusable = false;
             break;

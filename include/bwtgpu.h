@@ -182,6 +182,12 @@ uint8_t* bwtgpu_pipeline_input(bwtgpu_pipeline* p, int slot);
 size_t bwtgpu_pipeline_input_capacity(const bwtgpu_pipeline* p);
 /* Enqueues upload + transform + download of the first `bytes` bytes of the slot's input. */
 int bwtgpu_pipeline_submit(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter);
+/* bwtgpu_pipeline_submit and bwtgpu_pipeline_collect in one call, for a caller with nothing to do in between (a
+ * file of one slab).  Knowing that the caller waits, the library may pick a route that answers sooner but
+ * occupies the calling thread meanwhile (a batch of few large blocks is then sorted by a sequence of launches
+ * driven from the host, which beats the resident kernel that bwtgpu_pipeline_submit enqueues). */
+int bwtgpu_pipeline_run(bwtgpu_pipeline* p, int slot, size_t bytes, uint8_t delimiter, const uint8_t** out,
+                        size_t* out_bytes);
 /* Uploads the first `bytes` bytes of the slot's input and returns their byte-presence mask
  * (as bwtgpu_find_unused_byte does; synchronous).  A bwtgpu_pipeline_submit of the same slot
  * with the same byte count that follows uses the uploaded bytes instead of uploading again:

@@ -717,6 +717,10 @@ def test_slab_pipeline_entry_points(orc):
             assert L.bwtgpu_pipeline_collect(fwd, slot, ctypes.byref(out), ctypes.byref(n)) == 0
             got = ctypes.string_at(out.value, n.value)
             assert got == want[1:], (slot, staged)
+        # submit and collect in one call (the caller waits: the library may take a route that blocks)
+        ctypes.memmove(L.bwtgpu_pipeline_input(fwd, 1), data.ctypes.data, data.size)
+        assert L.bwtgpu_pipeline_run(fwd, 1, data.size, want[0], ctypes.byref(out), ctypes.byref(n)) == 0
+        assert ctypes.string_at(out.value, n.value) == want[1:]
         ctypes.memmove(L.bwtgpu_pipeline_input(inv, 0), got, len(got))
         assert L.bwtgpu_pipeline_submit(inv, 0, len(got), want[0]) == 0
         assert L.bwtgpu_pipeline_submit(inv, 0, len(got), want[0]) != 0  # not collected yet
