@@ -722,10 +722,15 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
                 if (i < w) below += c;
             }
             const bool delim_seen = ((sh.ball[a.delim >> 6] >> (a.delim & 63u)) & 1ull) != 0ull;
-            if (!delim_seen && (sigma == 1u || (sigma <= 4u && sh.flat > kLdsMaxFlat))) {
-                // one byte value throughout (as far as the sample shows) or in long stretches: runs, the other launches'
-                // business -- the common-case one's first, which puts off what it has to: a block like that takes its
-                // time there, and two launches that each wait for one of them take twice as long as one with both
+            if (!delim_seen && sigma == 1u) {
+                // one byte value throughout, as far as the sample shows: a run, the business of the launch for those --
+                // unless the batch is so small that every block has a workgroup to itself: then the two launches' slowest
+                // blocks are all that counts, and one launch that starts them all at once does better (see below)
+                tried = a.nblocks > gridDim.x;
+            } else if (!delim_seen && sigma <= 4u && sh.flat > kLdsMaxFlat) {
+                // long stretches of one value among other bytes: runs again, but left to the common-case launch, which puts off
+                // what it has to -- a block like that takes its time wherever it goes, and blocks of this kind next to the ones
+                // above would make two launches wait for a slow block each (a scanned page in 16 KiB blocks: 2.8 against 1.5 ms)
             } else if (!delim_seen && sigma <= 4u) {
                 if (tid < 256) {
                     const uint32_t code = below + (uint32_t)__popcll(bal & lanemask_lt());
