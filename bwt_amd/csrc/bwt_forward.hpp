@@ -1546,6 +1546,14 @@ __device__ __noinline__ void fill_unique_ranks(const FineIndex& fx, const Round0
 template <int NT>
 __device__ __forceinline__ uint32_t cut_chunks(const uint64_t* __restrict__ cur, uint32_t m, int gshift,
                                                uint32_t cap, uint32_t* __restrict__ start, FwdShared<NT>& sh) {
+    if (m <= cap) {  // workgroup-uniform: the whole list is one chunk, however long its groups are
+        if (threadIdx.x == 0) {
+            start[0] = 0;
+            start[1] = m;
+        }
+        __syncthreads();
+        return 1;
+    }
     const uint32_t nominal = max(cap - cap / 6u, (m + (uint32_t)kMaxBuckets - 2u) / ((uint32_t)kMaxBuckets - 1u));
     if (nominal > cap) return 0;  // workgroup-uniform
     const uint32_t slack = cap - nominal;
@@ -1795,7 +1803,16 @@ __device__ __noinline__ void build_next_break(uint32_t* __restrict__ next_break,
 // number of suffixes left (== m: nothing was resolved and `list` is still the list; else the
 // list is now in `spare`).
 constexpr uint32_t kMaxPeriod = 256;  // the break of the period is searched by one lane per group
-constexpr uint32_t kPeriodicMinBlock = 32768;  // shorter blocks never take the periodic-run step
+constexpr uint32_t kPeriodicMinBlock = 32768;  // wide workgroups (batches of few blocks): shorter blocks never take the periodic-run step
+// Batches of many blocks (256-thread workgroups) take it from 8 KiB: a block of a few repeated bytes that goes through
+// all its doubling rounds by radix passes over device memory holds its workgroup 10-15 times as long as other blocks
+// (1 GiB of period-7 text in 16 KiB blocks: 361 -> 27 ms, in 8 KiB blocks 204 -> 86 ms).  In a batch of few blocks a
+// put-off block is started over by a second launch while the chip idles, and a block of runs with exceptions (a scanned
+// page) gains nothing from the step: there the bound stays.
+template <int NT>
+__device__ __forceinline__ constexpr uint32_t periodic_min_block() {
+    return NT > 256 ? kPeriodicMinBlock : 8192u;
+}
 constexpr uint32_t kFewGroups = 256;     // a round through HBM with at most this many groups: periodic text, most likely
 constexpr uint32_t kTableGroups = 2048;  // more groups than this: no table, one thread walks each (short) group
 constexpr uint32_t kPeriodGood = 0x80000000u, kPeriodAsc = 0x40000000u, kPeriodMask = 0x00FFFFFFu;
@@ -2328,10 +2345,13 @@ __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__
         uint32_t best = (score << 8) | (uint32_t)(63 - lane);  // ties: the earliest
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor(best, o));
-        if (lane == 0) sh.period_cand = 64u * (63u - (best & 255u));
+        if (lane == 0) sh.period_cand = (64u * (63u - (best & 255u))) | ((best >> 8) == 0u ? 0x80000000u : 0u);
     }
     __syncthreads();
-    const uint32_t i0 = sh.period_cand;
+    const uint32_t i0 = sh.period_cand & 0x7FFFFFFFu;
+    // (all sixteen windows inside runs: the window occurs again at every step of its run, and every such candidate but
+    // the first fails where the run ends -- two tries, not sixteen sweeps that each find the next place at once)
+    const uint32_t tries = (sh.period_cand >> 31) ? 2u : kPeriodTries;
     __syncthreads();
     const uint8_t* pat = s + i0;
     const uint32_t pat0 = (uint32_t)pat[0] | ((uint32_t)pat[1] << 8) | ((uint32_t)pat[2] << 16) | ((uint32_t)pat[3] << 24);
@@ -2340,7 +2360,7 @@ __device__ __noinline__ uint32_t detect_block_period(const uint8_t* __restrict__
     constexpr int U = 4;  // dword pairs whose loads are issued together
     uint32_t from = 0;  // candidates up to here have been tried
 #pragma unroll 1
-    for (uint32_t attempt = 0; attempt < kPeriodTries; ++attempt) {
+    for (uint32_t attempt = 0; attempt < tries; ++attempt) {
         if (tid == 0) {
             sh.period_cand = 0xFFFFFFFFu;
             sh.period_bad = 0;
@@ -2590,7 +2610,7 @@ __device__ __forceinline__ void forward_block(const uint8_t* __restrict__ s_bloc
     const uint8_t* __restrict__ s = s_block;
     uint32_t len = len_block;
     uint32_t block_period = 0, period_tail = 0;
-    if (HEAVY && len_block >= kPeriodicMinBlock) {
+    if (HEAVY && len_block >= periodic_min_block<NT>()) {
         block_period = detect_block_period<NT>(s_block, len_block, a.in, a.in + a.total_len, sh);
         period_tail = block_period >= kShortTailMinPeriod ? kShortTail : block_period;
         pc.lap(19);
@@ -2709,7 +2729,7 @@ restart:
     }
     // a bucket with a sixteenth of the block under one key prefix: a dominant key (text has buckets
     // too long for LDS as well, but not of that size; those are sorted through HBM right here)
-    if (!HEAVY && !fused && longest_bucket > n / 16u && n >= kPeriodicMinBlock) {  // workgroup-uniform
+    if (!HEAVY && !fused && longest_bucket > n / 16u && n >= periodic_min_block<NT>()) {  // workgroup-uniform
         put_off();
         return;
     }
@@ -2833,7 +2853,7 @@ restart:
         // rerank has written them all when every bucket held many tied suffixes; else the missing ones
         // are looked up.  (Nearly) every suffix with a twin is repeated text, which the common-case
         // kernel leaves to the other one.
-        if (!HEAVY && n >= kPeriodicMinBlock && m >= n - 64u) {  // workgroup-uniform
+        if (!HEAVY && n >= periodic_min_block<NT>() && m >= n - 64u) {  // workgroup-uniform
             put_off();
             return;
         }
@@ -2842,7 +2862,7 @@ restart:
     } else if (!fused || m > n / 16u) {
         // (nearly) every suffix with a twin after round 0 is repeated text: the common-case kernel
         // learns that from the count and leaves the block to the other one before the costly sweep
-        const uint32_t bail_at = !HEAVY && n >= kPeriodicMinBlock ? n - 64u : 0xFFFFFFFFu;
+        const uint32_t bail_at = !HEAVY && n >= periodic_min_block<NT>() ? n - 64u : 0xFFFFFFFFu;
         rerank<NT, true>(sorted0, spare, rank, io, n, ibits, kshift0, gshift, periodic, bail_at, sh, m, G, full);
         if (!HEAVY && m >= bail_at) {  // workgroup-uniform
             put_off();
@@ -2910,7 +2930,7 @@ restart:
         // ... and a text in which (nearly) every suffix still has a twin after round 0 is repeated text
         const bool all_twins = round == 1 && n - m <= 64u;
         // (short blocks go through their rounds inside LDS faster than the step's sweeps and barriers take)
-        const bool suspect = n >= kPeriodicMinBlock && full && (stalled || (nchunks == 0 && (G <= kFewGroups || all_twins)));
+        const bool suspect = n >= periodic_min_block<NT>() && full && (stalled || (nchunks == 0 && (G <= kFewGroups || all_twins)));
         if (!HEAVY && suspect) {  // workgroup-uniform
             put_off();
             return;

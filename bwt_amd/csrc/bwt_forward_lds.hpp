@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
         // throughout, which that launch would only notice after a wasted round: looked for here (reads up to
         // kLdsMaxPeriod + 1 KiB of the block; a full comparison only if the unit is found again).
         bool heavy = tried;
-        if (!done && !tried && len >= kPeriodicMinBlock)
+        if (!done && !tried && len >= (a.nblocks > gridDim.x ? periodic_min_block<256>() : kPeriodicMinBlock))  // (as the launches behind this one)
             heavy = detect_block_period<kLdsThreads>(s, len, a.in, a.in + a.total_len, sh, kLdsMaxPeriod) != 0u;
         if (tid == 0 && !done) {
             if (heavy) a.deferred[atomicAdd(&a.queue[2], 1u)] = b;
