@@ -547,6 +547,29 @@ def test_periodic_runs(orc):
             assert api.inverse_batch(got, bs, delim) == data
 
 
+def test_small_periodic_blocks_in_large_batches(orc):
+    """Batches of more blocks than compute units take the periodic-run step from 8 KiB blocks (batches of few
+    blocks from 32 KiB): periods 1, 7 and 64 at block sizes on both sides of that bound, runs with exceptions
+    (a scanned page's zeros), periodic blocks among ordinary ones, a ragged tail."""
+    rng = np.random.default_rng(777)
+    page = np.frombuffer(open(os.path.join(CORPUS, "ptt5"), "rb").read(), np.uint8)
+    unit64 = rng.integers(0, 255, size=64, dtype=np.uint8)
+    for bs in (8191, 8192, 8193, 12000, 16384, 20000):
+        nblocks = 300
+        n = nblocks * bs + 1234
+        mixed = rng.integers(0, 200, size=n, dtype=np.uint8)
+        for b in range(0, nblocks, 3):  # every third block periodic, the others random bytes
+            mixed[b * bs:(b + 1) * bs] = np.resize(np.frombuffer(b"abcdefg", np.uint8), bs)
+        for arr in (np.full(n, 97, np.uint8), np.resize(np.frombuffer(b"abcdefg", np.uint8), n), np.resize(unit64, n),
+                    np.resize(page, n), mixed):
+            data = arr.tobytes()
+            want = orc.forward_buffer(data, bs, 8)
+            delim, want = want[0], want[1:]
+            got = api.forward_batch(data, bs, delim)
+            assert got == want, (bs, int(arr[0]), int(arr[1]))
+            assert api.inverse_batch(got, bs, delim) == data
+
+
 def test_whole_block_periods(orc):
     """Blocks whose text is periodic throughout are sorted through their last two periods only:
     periods from 1 to a third of the block, lengths that are no multiple of the period, delimiters
