@@ -48,6 +48,9 @@ WORKLOADS = {
     # not a BASELINE config: the shape of a single file (few large blocks), which takes the device-wide
     # forward path and the tiled inverse table build instead of the one-workgroup-per-block kernels
     "acgt-16m-1m": ("acgt", 1024 * 1024, 16 * MIB, 3, "16 MiB ACGT text, 1 MiB blocks: few large blocks (one file)"),
+    # not a BASELINE config: natural text (alice29.txt repeated; a block is shorter than the file, so no block holds a
+    # repeat of its own), which none of the in-LDS forward kernels takes -- the general kernels' rate on real text
+    "text-1g-64k": ("text", 64 * 1024, 1 * GIB, 1, "1 GiB of alice29.txt repeated, 64 KiB blocks (natural text through the general kernels)"),
     # BASELINE configs[0]: the reference's own CPU-runnable case (bytes per GPU = the file's length)
     "alice29-128k": ("file:alice29.txt", 128 * 1024, 0, 1, "Canterbury alice29.txt, 128 KiB blocks (BASELINE configs[0])"),
 }
