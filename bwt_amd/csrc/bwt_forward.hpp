@@ -2720,19 +2720,24 @@ restart:
     dir.flo = dir.start + (kMaxBuckets + 1);
     dir.fstart = dir.flo + (kMaxBuckets + 1);
     assign_buckets<NT>(sh, n, target, fbits, dir);
-    bool fused = true;  // every bucket fits LDS
+    bool all_fit = true;  // every bucket fits LDS
     uint32_t longest_bucket = 0;
     for (uint32_t k = 0; k < dir.nb; ++k) {
         const uint32_t cnt = dir.start[k + 1] - dir.start[k];
-        fused = fused && cnt <= (uint32_t)FwdShared<NT>::kSortCap;
+        all_fit = all_fit && cnt <= (uint32_t)FwdShared<NT>::kSortCap;
         longest_bucket = max(longest_bucket, cnt);
     }
     // a bucket with a sixteenth of the block under one key prefix: a dominant key (text has buckets
     // too long for LDS as well, but not of that size; those are sorted through HBM right here)
-    if (!HEAVY && !fused && longest_bucket > n / 16u && n >= periodic_min_block<NT>()) {  // workgroup-uniform
+    if (!HEAVY && !all_fit && longest_bucket > n / 16u && n >= periodic_min_block<NT>()) {  // workgroup-uniform
         put_off();
         return;
     }
+#ifdef BWT_SEPARATE_LONG_BUCKETS  // the earlier way: one bucket too long for LDS, and the whole block's rerank is a sweep of its own
+    const bool fused = all_fit;
+#else
+    const bool fused = true;  // buckets too long for LDS go through the fused rerank piece by piece (rerank_long_bucket)
+#endif
 #ifdef BWT_OLD_TWO_PASS
     const bool two_pass = dir.nb > (uint32_t)kBins;
     const int b1 = two_pass ? 4 : kMaxDigitBits;
@@ -2810,20 +2815,90 @@ restart:
     uint32_t* const nk = reinterpret_cast<uint32_t*>(sorted0);
     const FineIndex fx{dir.fstart, nk, r0.fshift};
     bool ranks_skipped = false;
+    // A bucket too long for the LDS sort (text has such: a pair of frequent letters, a run of blanks) is put in order
+    // through device memory and then goes through the same sort + rerank as the others piece by piece: pieces of whole
+    // key runs of at most the sort's capacity, cut where one thread's binary searches find the run borders (sorting a
+    // sorted piece again costs a few microseconds; what it buys is that the block keeps the fused rerank's narrow
+    // write-back and is spared a separate sweep over all its suffixes).  A run of ONE key longer than a piece needs
+    // neither order nor neighbours: its suffixes get the row of its first one and stay one group.
     for (uint32_t k = 0; k < dir.nb; ++k) {
         const uint32_t s0 = dir.start[k], cnt = dir.start[k + 1] - s0;
         if (cnt == 0) continue;  // workgroup-uniform
         const uint32_t f0 = dir.flo[k], f1 = dir.flo[k + 1];
         const uint64_t base = (uint64_t)f0 << r0.fshift;
         const int bits = r0.fshift + bit_length(f1 - f0 - 1u);
-        if (cnt <= (uint32_t)FwdShared<NT>::kSortCap) {
-            int up;
-            uint64_t bsub;
-            lds_sort_bucket<NT>(sorted0 + s0, cnt, kshift0, base, bits, sh, up, bsub);
-            pc.lap(12);
-            if (fused) rerank_bucket<NT>(sorted0 + s0, nk, narrow ? r0.fshift : -1, s0, cnt, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic, sh, m, G, ranks_skipped);
-            else store_bucket<NT>(sorted0 + s0, cnt, up, bsub, sh);
-            pc.lap(10);
+        constexpr uint32_t cap = (uint32_t)FwdShared<NT>::kSortCap;
+        if (cnt > cap) {  // workgroup-uniform
+            if (!fused) continue;
+            uint64_t* const a = sorted0 + s0;
+            if (!(HEAVY && settle_dominant_key<NT>(a, cnt, kshift0, sh))) sort_range_global<NT>(a, spare + s0, cnt, kshift0, base, bits, sh, &queue[1]);
+            pc.lap(11);
+        }
+        uint32_t pos = 0;
+        while (pos < cnt) {  // workgroup-uniform; once for a bucket that fits
+            uint32_t end = cnt;
+            bool equal = false;
+            if (cnt - pos > cap) {
+                const uint64_t* const a = sorted0 + s0;
+                if (tid == 0) {
+                    const uint32_t t = pos + cap;  // the first element that does not fit
+                    const uint64_t kt = a[t] >> kshift0;
+                    uint32_t lo = pos, hi = t;  // where kt's run starts, if that is behind pos
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((a[mid] >> kshift0) < kt) lo = mid + 1u;
+                        else hi = mid;
+                    }
+                    uint32_t e2 = lo, eq = 0;
+                    if (lo == pos) {  // one key from pos to beyond what fits: where its run ends
+                        uint32_t l2 = t, h2 = cnt;
+                        while (l2 < h2) {
+                            const uint32_t mid = (l2 + h2) >> 1;
+                            if ((a[mid] >> kshift0) <= kt) l2 = mid + 1u;
+                            else h2 = mid;
+                        }
+                        e2 = l2;
+                        eq = 1;
+                    }
+                    sh.period_cand = e2;
+                    sh.period_bad = eq;
+                }
+                __syncthreads();
+                end = sh.period_cand;
+                equal = sh.period_bad != 0u;
+                __syncthreads();
+            }
+            const uint32_t c = end - pos;
+            if (!equal) {
+                int up;
+                uint64_t bsub;
+                lds_sort_bucket<NT>(sorted0 + s0 + pos, c, kshift0, base, bits, sh, up, bsub);
+                pc.lap(12);
+                if (fused) rerank_bucket<NT>(sorted0 + s0 + pos, nk, narrow ? r0.fshift : -1, s0 + pos, c, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic, sh, m, G, ranks_skipped);
+                else store_bucket<NT>(sorted0 + s0 + pos, c, up, bsub, sh);
+                pc.lap(10);
+            } else {
+                // (the narrow write-back of row r lands in the element of row r / 2: never ahead of the batch being read,
+                // but possibly inside it -- so a batch is read by everybody before anybody writes)
+                const uint64_t* const a = sorted0 + s0 + pos;
+                const uint64_t imask = (1ull << ibits) - 1ull;
+                for (uint32_t i0 = 0; i0 < c; i0 += NT) {
+                    const uint32_t i = i0 + (uint32_t)tid;
+                    const uint64_t e = i < c ? a[i] : 0ull;
+                    __syncthreads();
+                    if (i < c) {
+                        const uint32_t idx = (uint32_t)(e & imask);
+                        if (narrow) nk[s0 + pos + i] = (uint32_t)(e >> kshift0) & (uint32_t)((1ull << r0.fshift) - 1ull);
+                        rank[idx] = s0 + pos;
+                        spare[m + i] = ((uint64_t)G << gshift) | idx;
+                    }
+                }
+                m += c;
+                G += 1u;
+                __syncthreads();
+                pc.lap(10);
+            }
+            pos = end;
         }
     }
     if (!fused) {

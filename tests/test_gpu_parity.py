@@ -497,6 +497,22 @@ def test_skewed_distributions_and_many_blocks(orc):
     vocab = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(50)]
     e = b" ".join(vocab[int(i)] for i in rng.integers(0, 50, size=60000))
     cases.append((e, 262144))
+    # round-0 buckets too long for the LDS sort, taken through the fused rerank piece by piece: a run of one key longer
+    # than a piece among random bytes (few blocks: 1024-thread workgroups; many blocks: 256-thread ones, blocks below the
+    # size from which such blocks are put off), several long buckets side by side (words over few first letters),
+    # a long run at the block's very start and at its very end
+    g = rng.integers(0, 250, size=24000, dtype=np.uint8)
+    g[3000:3000 + 9000] = 32
+    cases.append((g.tobytes(), 24000))
+    cases.append((np.tile(g[:7900], 300).tobytes(), 7900))
+    h = np.concatenate([np.full(6000, 1, np.uint8), rng.integers(2, 250, size=12000, dtype=np.uint8), np.full(6000, 251, np.uint8)])
+    cases.append((h.tobytes(), 24000))
+    cases.append((np.tile(h[:7000], 280).tobytes() + h.tobytes(), 7000))
+    few = [bytes([97 + int(rng.integers(0, 2)), 97 + int(rng.integers(0, 2))]) + bytes(rng.integers(97, 123, size=int(rng.integers(1, 7)), dtype=np.uint8))
+           for _ in range(400)]
+    w = b"".join(few[int(i)] for i in rng.integers(0, 400, size=40000))
+    cases.append((w[:200000], 65536))
+    cases.append((w[:300 * 7500], 7500))
     for data, bs in cases:
         want = orc.forward_buffer(data, bs, 8)
         delim = want[0]
