@@ -3045,18 +3045,32 @@ restart:
             const uint64_t imask = (1ull << ibits) - 1ull;
             uint32_t* myhist = sh.hist[0] + w * kBins;
             if (full) {
-                for (uint32_t base = lo; base < hi; base += kWave) {
-                    const uint32_t k = base + lane;
-                    if (k < hi) {
-                        uint64_t e = alt[k];
-                        const uint32_t idx = (uint32_t)(e & imask);
-                        const uint32_t j = idx + h;
-                        uint32_t r2 = j < n ? rank[j] + 1u : 0u;
-                        if (tail_fix && first && j >= r0.nm && j < n) r2 = sh.tailrow[j - r0.nm] + 1u;
-                        if (idx >= r0.nm) r2 = tail_order(r0, idx);
-                        e |= (uint64_t)r2 << ibits;
-                        alt[k] = e;
-                        atomicAdd(&myhist[(uint32_t)(e >> ibits) & dmask], 1u);
+                // four elements per lane at a time: their reads of the list, then their lookups in the rank array, are
+                // in flight together (one after the other, every lookup waited out a trip to the L2 on its own)
+                constexpr int U = 4;
+                for (uint32_t base = lo; base < hi; base += U * kWave) {
+                    uint64_t e[U];
+                    uint32_t r2[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) e[u] = alt[min(base + (uint32_t)(u * kWave + lane), m - 1u)];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t j = (uint32_t)(e[u] & imask) + h;
+                        r2[u] = j < n ? rank[j] + 1u : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t k = base + (uint32_t)(u * kWave + lane);
+                        if (k < hi) {
+                            const uint32_t idx = (uint32_t)(e[u] & imask);
+                            const uint32_t j = idx + h;
+                            uint32_t r = r2[u];
+                            if (tail_fix && first && j >= r0.nm && j < n) r = sh.tailrow[j - r0.nm] + 1u;
+                            if (idx >= r0.nm) r = tail_order(r0, idx);
+                            const uint64_t x = e[u] | ((uint64_t)r << ibits);
+                            alt[k] = x;
+                            atomicAdd(&myhist[(uint32_t)(x >> ibits) & dmask], 1u);
+                        }
                     }
                 }
             } else {
