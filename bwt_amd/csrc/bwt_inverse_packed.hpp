@@ -474,6 +474,30 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
         __syncthreads();
         const uint32_t cbytes = sh.cb[0] | (sh.cb[1] << 8) | (sh.cb[2] << 16) | (sh.cb[3] << 24);
 
+        // Four rows at a time where the alphabet allows it: if some two bits of the byte values (bits fs, fs + 1) tell
+        // the block's symbols apart -- A C G T: bits 1 and 2 --, the four fields of a dword of rows index a table of 256
+        // words: the four codes as a byte-permute selector (bits 0-1 of every byte), the codes' low bits (bits 4-7) and
+        // high bits (bits 12-15).  The selector turns the codes back into bytes; a dword that does not come back as it
+        // was holds the delimiter or a byte outside the alphabet, and its rows go the byte-by-byte way below.
+        uint32_t fs = 8;  // no such field
+        for (uint32_t f = 0; f < 7u && fs == 8u; ++f) {
+            uint32_t seen = 0;
+            for (uint32_t i = 0; i < sigma; ++i) seen |= 1u << (((cbytes >> (8u * i)) >> f) & 3u);
+            if ((uint32_t)__popc(seen) == sigma) fs = f;
+        }
+        uint32_t* const quad = sh.seg;  // (the segment records are set up after this step)
+        if (fs < 8u && tid < 256) {
+            uint32_t word = 0;
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t field = ((uint32_t)tid >> (2u * k)) & 3u;
+                uint32_t code = 0;
+                for (uint32_t i = 0; i < sigma; ++i)
+                    if ((((cbytes >> (8u * i)) >> fs) & 3u) == field) code = i;
+                word |= (code << (8u * k)) | ((code & 1u) << (4u + k)) | ((code >> 1) << (12u + k));
+            }
+            quad[tid] = word;
+        }
+        __syncthreads();
         PACK_CLK(0);
         // ---- pack: 16 rows per lane and step, the delimiter row still in (code 0)
         const uint32_t groups = (n + 63u) / 64u;
@@ -490,12 +514,32 @@ __global__ __launch_bounds__(kPackThreads) void bwt_inverse_packed_kernel(InvArg
                     for (uint32_t k = 0; r0 + k < n; ++k)
                         d[k >> 2] = (d[k >> 2] & ~(255u << (8u * (k & 3u)))) | ((uint32_t)L[r0 + k] << (8u * (k & 3u)));
                 }
+                bool by_byte = true;
+                if (fs < 8u) {
+                    uint32_t e[4], diff = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) {
-                    const uint32_t c = sh.lut[(d[k >> 2] >> (8u * (k & 3u))) & 255u];
-                    lo |= (c & 1u) << k;
-                    hi |= ((c >> 1) & 1u) << k;
-                    fl |= c;
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t t = (d[j] >> fs) & 0x03030303u;
+                        const uint32_t y = t | (t >> 6);
+                        e[j] = quad[(y | (y >> 12)) & 255u];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        diff |= __builtin_amdgcn_perm(0u, cbytes, e[j] & 0x03030303u) ^ d[j];
+                        lo |= ((e[j] >> 4) & 15u) << (4 * j);
+                        hi |= ((e[j] >> 12) & 15u) << (4 * j);
+                    }
+                    by_byte = diff != 0u;
+                }
+                if (by_byte) {
+                    lo = hi = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) {
+                        const uint32_t c = sh.lut[(d[k >> 2] >> (8u * (k & 3u))) & 255u];
+                        lo |= (c & 1u) << k;
+                        hi |= ((c >> 1) & 1u) << k;
+                        fl |= c;
+                    }
                 }
                 if (fl & 0x84u) {  // rare: a delimiter, or a byte that is not in the alphabet
                     if (fl & 0x80u) sh.bad = 1;
