@@ -103,6 +103,7 @@ struct LdsShared {
     } u;
     uint8_t present[256];
     uint8_t code[256];             // byte -> code 0..3; 0x80: not in the alphabet (the delimiter included)
+    uint32_t quad[256];            // two-bit text: four two-bit fields of a dword of text -> its four codes (see the pack step)
     uint32_t wsum[kLdsWaves];
     uint64_t ball[4];
     uint32_t cb[4];                // code -> byte
@@ -349,22 +350,13 @@ __device__ __forceinline__ void lds_sort_bucket(LdsShared& sh, LdsWaveArea& wa, 
     wave_sync();
 }
 
-// One block.  Returns false when the block is given up (workgroup-uniform).
+// The pack step of one block (see lds_forward_block), a function of its own: the kernel around it sits at its register
+// limit, and inlined, this step's temporaries moved the allocation of the sort phase for the worse (17.7 -> 18.8 ms).
 template <int BITS>
-__device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
-                                                  uint8_t* __restrict__ out, uint32_t* sa, LdsShared& sh, uint32_t sigma,
-                                                  uint32_t dr, uint32_t cbytes, PhaseClock& pc) {
-    constexpr int PW = LdsFmt<BITS>::kPerWord, WS = LdsFmt<BITS>::kWordShift;
-    int tid = (int)opaque(threadIdx.x);
-    const int w = wave_id();
-    const uint32_t n = len + 1u;
-    const bool above = BITS == 2 && dr == sigma;
-    const uint32_t top = (1u << BITS) - 1u;
-    // the virtual symbols at position len and behind it
-    const uint32_t vd = BITS == 8 ? delim : above ? top : dr, vfill = above ? top : 0u;
-    const uint32_t nwords = (len >> WS) + 3u;  // a window at position len reads the word of len and the next one
-
-    // ---- pack ----------------------------------------------------------------------------------
+__device__ __attribute__((noinline)) void lds_pack_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim, LdsShared& sh,
+                                                          uint32_t cbytes, uint32_t fs, uint32_t vd, uint32_t vfill, uint32_t nwords) {
+    constexpr int PW = LdsFmt<BITS>::kPerWord;
+    const int tid = threadIdx.x;
     for (uint32_t i = (uint32_t)tid; i < kLdsFine; i += kLdsThreads) sh.u.fine[i] = 0;
     {
         uint32_t flags = 0;
@@ -415,6 +407,22 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (4u * v + (uint32_t)k < kLdsTextWords) sh.text[4u * v + (uint32_t)k] = wd[k];
+                } else if (fs < 8u && p0 + 16u <= len) {
+                    // four symbols at a time: bits fs, fs + 1 of the byte values tell the block's symbols apart, so the
+                    // four fields of a dword index a table of its four codes -- as a byte-permute selector, which turns
+                    // them back into bytes (a dword that does not come back as it was holds a byte outside the alphabet),
+                    // and packed the way the text word wants them (bits 2-7, the last code being the selector's top byte)
+                    uint32_t word = 0, diff = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t t = (d[u][j] >> fs) & 0x03030303u;
+                        const uint32_t y = t | (t >> 6);
+                        const uint32_t e = sh.quad[(y | (y >> 12)) & 255u];
+                        diff |= __builtin_amdgcn_perm(0u, cbytes, e & 0x03030303u) ^ d[u][j];
+                        word |= ((e & 0xFCu) | (e >> 24)) << (24 - 8 * j);
+                    }
+                    if (diff) flags |= 0x80u;
+                    sh.text[v] = word;
                 } else {
                     uint32_t word = 0;
 #pragma unroll
@@ -431,6 +439,25 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
         }
         if (flags & 0x80u) sh.bad = 1;
     }
+}
+
+// One block.  Returns false when the block is given up (workgroup-uniform).
+template <int BITS>
+__device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s, uint32_t len, uint32_t delim,
+                                                  uint8_t* __restrict__ out, uint32_t* sa, LdsShared& sh, uint32_t sigma,
+                                                  uint32_t dr, uint32_t cbytes, uint32_t fs, PhaseClock& pc) {
+    constexpr int PW = LdsFmt<BITS>::kPerWord, WS = LdsFmt<BITS>::kWordShift;
+    int tid = (int)opaque(threadIdx.x);
+    const int w = wave_id();
+    const uint32_t n = len + 1u;
+    const bool above = BITS == 2 && dr == sigma;
+    const uint32_t top = (1u << BITS) - 1u;
+    // the virtual symbols at position len and behind it
+    const uint32_t vd = BITS == 8 ? delim : above ? top : dr, vfill = above ? top : 0u;
+    const uint32_t nwords = (len >> WS) + 3u;  // a window at position len reads the word of len and the next one
+
+    // ---- pack ----------------------------------------------------------------------------------
+    lds_pack_block<BITS>(s, len, delim, sh, cbytes, fs, vd, vfill, nwords);
     __syncthreads();
     if (sh.bad) return false;  // workgroup-uniform
     pc.lap(kLdsClockSlot + 1);
@@ -755,15 +782,35 @@ __global__ __launch_bounds__(kLdsThreads) void bwt_forward_lds_kernel(FwdArgs a)
                 uint32_t dr = 0;  // text symbols below the delimiter
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) dr += (i < sigma && ((cbytes >> (8u * i)) & 255u) < a.delim) ? 1u : 0u;
+                // a two-bit field of the byte values that tells the symbols apart (A C G T: bits 1 and 2), and the table
+                // of the pack step's four-at-a-time path over it
+                uint32_t fs = 8;  // none
+                for (uint32_t f = 0; f < 7u && fs == 8u; ++f) {
+                    uint32_t seen = 0;
+                    for (uint32_t i = 0; i < sigma; ++i) seen |= 1u << (((cbytes >> (8u * i)) >> f) & 3u);
+                    if ((uint32_t)__popc(seen) == sigma) fs = f;
+                }
+                if (fs < 8u && tid < 256) {
+                    uint32_t word = 0;
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t field = ((uint32_t)tid >> (2u * k)) & 3u;
+                        uint32_t code = 0;
+                        for (uint32_t i = 0; i < sigma; ++i)
+                            if ((((cbytes >> (8u * i)) >> fs) & 3u) == field) code = i;
+                        word |= (code << (8u * k)) | (k < 3u ? code << (6u - 2u * k) : 0u);
+                    }
+                    sh.quad[tid] = word;
+                }
+                __syncthreads();
                 pc.lap(kLdsClockSlot + 0);
                 tried = true;
-                done = lds_forward_block<2>(s, len, a.delim, out, sa, sh, sigma, dr, cbytes, pc);
+                done = lds_forward_block<2>(s, len, a.delim, out, sa, sh, sigma, dr, cbytes, fs, pc);
             } else if (!delim_seen && len <= kLdsMaxLen8 && sh.dups <= kLdsMaxDups) {
                 // (bytes whose four-byte strings repeat would fill single sub-bins of the bucket sort beyond what it settles,
                 // and the block would be given up after most of the work: left to the general kernels untried)
                 pc.lap(kLdsClockSlot + 0);
                 tried = true;
-                done = lds_forward_block<8>(s, len, a.delim, out, sa, sh, 256u, a.delim, 0u, pc);
+                done = lds_forward_block<8>(s, len, a.delim, out, sa, sh, 256u, a.delim, 0u, 8u, pc);
             }
         }
         // Where a block that is not finished goes.  One that was tried and given up has overfull buckets or
