@@ -256,6 +256,11 @@ def test_text_in_lds_forward(orc, forward_path):
     runny = draw(b"ACGT", 150000).copy()
     runny[50000:90000] = ord("C")
     cases.append((runny, 255))
+    # mildly skewed symbol frequencies: the fullest bucket target does not fit, a smaller one does (or none does and
+    # the block is left to the general kernels)
+    for probs in [(0.3, 0.3, 0.2, 0.2), (0.35, 0.3, 0.2, 0.15), (0.4, 0.3, 0.2, 0.1), (0.5, 0.25, 0.15, 0.1)]:
+        for n in (65536, 262144):
+            cases.append((np.frombuffer(b"ACGT", np.uint8)[rng.choice(4, size=n, p=probs)], 0))
     for arr, delim in cases:
         data = arr.astype(np.uint8).tobytes()
         want = orc.forward(data, delim)
