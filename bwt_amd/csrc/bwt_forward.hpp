@@ -2733,6 +2733,33 @@ restart:
         put_off();
         return;
     }
+    // Will more than a sixteenth of the suffixes stay tied after this round?  Then the rounds to come read the rank of
+    // any suffix, and a bucket that skipped the ranks of its finished suffixes (the fused rerank's choice per bucket,
+    // right for uniform keys) leaves them to be looked up one by one afterwards -- 100 of 165 ms per GiB for four
+    // symbols with frequencies 0.4 / 0.3 / 0.2 / 0.1.  An estimate from the fine bins: for independent symbols the
+    // chance that two suffixes share their fine bin is S = sum of (bin / n)^2, the chance that they share the whole
+    // key is S ^ (key bits / fine bits), and a suffix has n - 1 others to share it with.  Where that predicts ties in
+    // plenty every bucket writes all its ranks (text, whose repeats no such estimate sees, is left to the buckets'
+    // own counts as before; a wrong guess costs time, not correctness).
+    bool tie_heavy;
+    {
+        float part = 0.0f;
+        const float inv_n = 1.0f / (float)n;
+        for (uint32_t f = (uint32_t)tid; f < (uint32_t)kFine; f += NT) {
+            const float share = (float)(dir.fstart[f + 1u] - dir.fstart[f]) * inv_n;
+            part += share * share;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) sh.wsum[w] = __float_as_uint(part);
+        __syncthreads();
+        float S = 0.0f;
+#pragma unroll
+        for (int i = 0; i < W; ++i) S += __uint_as_float(sh.wsum[i]);
+        __syncthreads();
+        const float expo = (float)(m0 * sbits) / (float)max(fbits, 1);
+        tie_heavy = (float)n * __powf(S, expo) > 1.0f / 16.0f;
+    }
 #ifdef BWT_SEPARATE_LONG_BUCKETS  // the earlier way: one bucket too long for LDS, and the whole block's rerank is a sweep of its own
     const bool fused = all_fit;
 #else
@@ -2874,7 +2901,7 @@ restart:
                 uint64_t bsub;
                 lds_sort_bucket<NT>(sorted0 + s0 + pos, c, kshift0, base, bits, sh, up, bsub);
                 pc.lap(12);
-                if (fused) rerank_bucket<NT>(sorted0 + s0 + pos, nk, narrow ? r0.fshift : -1, s0 + pos, c, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic, sh, m, G, ranks_skipped);
+                if (fused) rerank_bucket<NT>(sorted0 + s0 + pos, nk, narrow ? r0.fshift : -1, s0 + pos, c, spare, rank, out, ibits, kshift0, gshift, up, bsub, periodic || tie_heavy, sh, m, G, ranks_skipped);
                 else store_bucket<NT>(sorted0 + s0 + pos, c, up, bsub, sh);
                 pc.lap(10);
             } else {
