@@ -62,6 +62,7 @@ constexpr uint32_t kLdsBuckets = kLdsThreads;    // lane t owns bucket t in the 
 constexpr uint32_t kLdsTarget = 288;             // suffixes per bucket the assign step aims at when nothing fuller fits ...
 constexpr uint32_t kLdsTargetMid = 352;          // ... after these two have been tried
 constexpr uint32_t kLdsTargetHigh = 448;
+constexpr uint32_t kLdsTargets = 5;             // attempts in all: the two above, kLdsTarget, and two more 64 and 128 below it
 constexpr uint32_t kLdsCap = 512;                // ... and the most a bucket may hold
 constexpr int kLdsSubBits = 9;
 constexpr uint32_t kLdsSub = 1u << kLdsSubBits;  // sub-bins of a bucket
@@ -492,8 +493,11 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
     uint32_t target = 0, nb = 0;
     uint32_t my_start = 0, my_end = 0, my_flo = 0;
 #pragma unroll 1
-    for (uint32_t attempt = 0; attempt < 3u; ++attempt) {
-        target = max(attempt == 0u ? kLdsTargetHigh : attempt == 1u ? kLdsTargetMid : kLdsTarget, (n + kLdsBuckets - 1u) / kLdsBuckets);
+    for (uint32_t attempt = 0; attempt < kLdsTargets; ++attempt) {
+        // 448, 352, 288, 224, 160 -- but never so low that the block would need more than kLdsBuckets buckets (a 256 KiB
+        // block: 257 at least, so its last two attempts repeat the third)
+        const uint32_t want = attempt == 0u ? kLdsTargetHigh : attempt == 1u ? kLdsTargetMid : kLdsTarget - 64u * (attempt - 2u);
+        target = max(want, (n + kLdsBuckets - 1u) / kLdsBuckets);
         nb = (n - 1u) / target + 1u;
         const uint32_t magic = 0xFFFFFFFFu / target + 1u;
         auto bucket_of = [&](uint32_t slot) {
@@ -540,7 +544,7 @@ __device__ __forceinline__ bool lds_forward_block(const uint8_t* __restrict__ s,
         const bool fits = sh.bad == 0u;  // workgroup-uniform
         __syncthreads();
         if (fits) break;
-        if (attempt == 2u) return false;  // a key prefix too common for a wave's bucket
+        if (attempt + 1u == kLdsTargets) return false;  // a key prefix too common for a wave's bucket
         if (tid == 0) sh.bad = 0;
         __syncthreads();
     }

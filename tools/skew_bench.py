@@ -4,7 +4,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from bwt_amd import api
 L = api.lib(); api.init(1)
-bs = 262144
+bs = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 n = 1 << 30
 torch.manual_seed(5)
 sym = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device='cuda')
