@@ -67,7 +67,7 @@ constexpr uint32_t kLdsCap = 512;                // ... and the most a bucket ma
 constexpr int kLdsSubBits = 9;
 constexpr uint32_t kLdsSub = 1u << kLdsSubBits;  // sub-bins of a bucket
 constexpr int kLdsFieldBits = 32 - kLdsSubBits;  // key bits an element keeps (beside its 9-bit index)
-constexpr uint32_t kLdsMaxBin = 64;              // a fuller sub-bin gives the block up (the round counts of the settle step are checked up to 96)
+constexpr uint32_t kLdsMaxBin = 128;             // a fuller sub-bin gives the block up (the round counts of the settle step are checked up to 160)
 constexpr int kLdsVecs = (int)(kLdsCap / 64u);   // 64-element vectors of the fullest bucket
 constexpr uint32_t kLdsGroup = 16;               // consecutive positions one lane handles in a sweep
 constexpr uint32_t kLdsTile = kLdsGroup * kLdsThreads;
@@ -211,7 +211,7 @@ __device__ __forceinline__ bool lds_suffix_less(const uint32_t* text, uint32_t p
 //            neighbours -- inside the lane, then across the lane border through DPP -- finish the order.
 //            Every round applies each neighbour pair once; for sub-bins of m elements (m + 1) / 2 rounds (E even) or
 //            m - 1 - (m - 1) / 4 rounds (E odd) sort every input: the network has adjacent comparators only, so it
-//            sorts everything if it sorts the reversed sequence, which was checked for all m <= 96, every E and
+//            sorts everything if it sorts the reversed sequence, which was checked for all m <= 160, every E and
 //            every place a sub-bin can start (E even is plain odd-even transposition, which needs m steps).
 //   rows     element x of the bucket stands in row s0 + x: the lane stores the byte before each of its
 //            suffixes; elements whose kept key bits tie are first put in order through the text.
