@@ -3120,8 +3120,10 @@ restart:
                     for (int u = 0; u < U; ++u) {
                         const uint32_t k = base + (uint32_t)(u * kWave + lane);
                         if (k < hi) {
-                            uint32_t r2 = j[u] < n ? rk[u] + 1u : 0u;
-                            if (tail_fix && j[u] >= r0.nm && j[u] < n) r2 = sh.tailrow[j[u] - r0.nm] + 1u;  // this path only runs in the first round
+                            // (after the first round a suffix that is not alone with its round-0 key has a rank of its
+                            // own, as fine as this round needs it, where the lookup only knows its round-0 row)
+                            uint32_t r2 = j[u] < n ? ((narrow && !first && !alone[u]) ? rank[j[u]] + 1u : rk[u] + 1u) : 0u;
+                            if (tail_fix && j[u] >= r0.nm && j[u] < n) r2 = sh.tailrow[j[u] - r0.nm] + 1u;  // (the exact rows of the suffixes that reach the delimiter within m0 symbols)
                             if (j[u] - h >= r0.nm) r2 = tail_order(r0, j[u] - h);
                             const uint64_t x = e[u] | ((uint64_t)r2 << ibits);
                             alt[k] = x;
@@ -3164,6 +3166,19 @@ restart:
             if (m2 == 0) break;
             // survivors remain after the searched round (rare: long repeats in otherwise easy data):
             // the rounds to come read rank[] of any suffix
+            if (narrow && !periodic) {
+                // A handful of suffixes inside repeats (DNA is full of them): the doubling goes on by lookup.  A suffix
+                // that shares its round-0 key with another has had its rank written by every round so far; one that is
+                // alone with its key has its row from the lookup itself -- so nobody needs the rank array completed,
+                // which is a lookup per suffix of the block (one repeat of 100 symbols in a 256 KiB block of DNA: 21 ms
+                // against 2.8 ms for the block).
+                cur = sorted;
+                alt = other;
+                m = m2;
+                G = G2;
+                h = (h >= 0x40000000u) ? 0x80000000u : h * 2u;
+                continue;
+            }
             if (narrow) {
                 // the tied suffixes have their ranks of this round; the others get their rows looked up,
                 // and the doubling goes on with the list at hand in the halves of `spare`

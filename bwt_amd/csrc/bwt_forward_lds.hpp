@@ -74,7 +74,7 @@ constexpr uint32_t kLdsTile = kLdsGroup * kLdsThreads;
 constexpr int kLdsPosBits = 19;                  // positions 0 .. 262144
 constexpr uint32_t kLdsPosMask = (1u << 19) - 1u;
 constexpr int kLdsCodeShift = 29;                // a scratch word: position | bucket << 19 | (two-bit text) code of the symbol before << 29
-constexpr int kLdsDepth = 8;                     // windows two suffixes are compared over before the block is given up
+constexpr int kLdsDepth = 32;                    // windows two suffixes are compared over before the block is given up (512 symbols of two-bit text, 128 bytes)
 constexpr uint32_t kLdsMaxDups = 110;            // byte alphabets: colliding sample windows (of 1024) up to which a block is tried
 constexpr uint32_t kLdsMaxFlat = 32;             // sample windows (of 1024) of one repeated byte up to which a block is tried
 constexpr uint32_t kLdsMaxPeriod = 4096;         // whole-block periods up to here are looked for before anything else
