@@ -526,6 +526,38 @@ def test_skewed_distributions_and_many_blocks(orc):
         assert api.inverse_batch(got, bs, delim) == data, (len(data), bs)
 
 
+def test_repeats_inside_blocks(orc):
+    """Blocks of otherwise random symbols with stretches copied elsewhere (several lengths from a few symbols to
+    thousands, overlapping copies, a copy that runs into the block's end): the few suffixes inside the repeats stay
+    tied for many doubling rounds, which the general kernels go through by looking ranks up instead of completing
+    the rank array.  Sizes above what the in-LDS kernel holds, so the general kernels see the blocks first, and
+    sizes it holds, so they see them after it has given up."""
+    rng = np.random.default_rng(909)
+    cases = []
+    for symbols, n in [(np.frombuffer(b"ACGT", np.uint8), 300000), (np.frombuffer(b"ACGT", np.uint8), 200000),
+                       (np.arange(1, 251, dtype=np.uint8), 70000), (np.arange(1, 251, dtype=np.uint8), 50000),
+                       (np.frombuffer(b"ACGTN", np.uint8), 150000)]:
+        a = symbols[rng.integers(0, len(symbols), size=n)].copy()
+        at = 1000
+        for length in (7, 13, 30, 61, 150, 400, 1100, 3000):
+            src = int(rng.integers(0, n - 4000))
+            dst = int(rng.integers(0, n - 4000))
+            a[dst:dst + length] = a[src:src + length]
+            at += length
+        a[5000:5600] = a[4800:5400]          # a copy that overlaps its source: period 200 for a while
+        a[n - 700:] = a[20000:20700]         # ... and one that ends with the block
+        cases.append((a, n))
+    batch = np.concatenate([c[0][:70000] for c in cases] * 60)  # many blocks: the 256-thread kernels
+    cases.append((batch, 70000))
+    for arr, bs in cases:
+        data = arr.tobytes()
+        want = orc.forward_buffer(data, bs, 8)
+        delim, want = want[0], want[1:]
+        got = api.forward_batch(data, bs, delim)
+        assert got == want, (len(data), bs)
+        assert api.inverse_batch(got, bs, delim) == data
+
+
 def test_periodic_runs(orc):
     """Long groups whose positions form an arithmetic progression are ordered in one step by the
     batch kernel: both directions, several periods in one block, periods that only qualify in a
