@@ -2959,8 +2959,12 @@ restart:
             put_off();
             return;
         }
-        if (ranks_skipped && !periodic) fill_unique_ranks<NT>(fx, r0, sh.sym, rank);
-        full = true;
+        // Buckets with few ties have skipped the ranks of their finished suffixes.  Completing the array is a lookup per
+        // suffix of the block; up to a quarter of the block tied (DNA with its repeats: 5-10 %), looking ranks up for
+        // the survivors of every round is less -- the list halves or better from round to round.
+        const bool by_lookup = ranks_skipped && !periodic && m <= n / 4u;
+        if (ranks_skipped && !periodic && !by_lookup) fill_unique_ranks<NT>(fx, r0, sh.sym, rank);
+        full = !by_lookup;
     } else if (!fused || m > n / 16u) {
         // (nearly) every suffix with a twin after round 0 is repeated text: the common-case kernel
         // learns that from the count and leaves the block to the other one before the costly sweep
